@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Headline benchmark: jacobi2d fp32 on an 8192 x 8192 grid, iterate = 100.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full pass of the hot path over one batch of synthetic input:
+all 100 iterations of the program on the whole grid, inputs resident in HBM.
+Metric: cells*iters/s (BASELINE.json).  N > 1: launched by torchrun, one rank
+per GPU; the same 8192^2 grid is cut into slabs along the streamed dimension
+(strong scaling) with halo exchange over RCCL (soda_amd/dist.py).
+
+Besides the contract's fields the JSON line carries
+  roofline      HBM roofline of the dominant kernel: algorithmic bytes per
+                launch / its average duration measured here with HIP events on
+                the launch stream;
+  cpu_baseline  the CPU oracle ("port" of the reference's loop nest, OpenMP on
+                all host cores) timed on a bounded sample -- rank 0, N = 1 only;
+  single_iter   the same workload with one iteration per launch (no temporal
+                blocking), for the "LDS/register halo tile" config of BASELINE.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--soda', default=os.path.join(
+      ROOT, 'tests', 'golden', 'soda', 'jacobi2d.soda'))
+  ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])
+  ap.add_argument('--iterate', type=int, default=100)
+  ap.add_argument('--fuse', type=int, default=4,
+                  help='iterations fused per launch (temporal blocking)')
+  ap.add_argument('--chunk-rows', type=int, default=64)
+  ap.add_argument('--prefetch', type=int, default=2)
+  ap.add_argument('--waves-x', type=int, default=1)
+  ap.add_argument('--waves-y', type=int, default=4)
+  ap.add_argument('--strategy', default='auto')
+  ap.add_argument('--exchange-every', type=int, default=20,
+                  help='iterations between halo exchanges (N > 1)')
+  ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-single-iter', action='store_true')
+  ap.add_argument('--cpu-seconds', type=float, default=12.0,
+                  help='target CPU time of the cpu_baseline sample')
+  return ap.parse_args()
+
+
+def time_events(fn, stream, repeats):
+  """Average milliseconds of fn() over `repeats` calls, HIP events recorded on
+  the stream the kernels are launched on."""
+  from soda_amd import runtime
+  start, stop = runtime.Event(), runtime.Event()
+  start.record(stream)
+  for _ in range(repeats):
+    fn()
+  stop.record(stream)
+  return start.elapsed_ms(stop) / repeats
+
+
+def cpu_baseline(stencil, extent, target_seconds):
+  """The CPU oracle on a bounded sample of the same workload."""
+  import numpy as np
+  from oracle import c_oracle
+  orc = c_oracle.COracle(stencil, openmp=True)
+  cores = orc.max_threads
+  rng = np.random.default_rng(0)
+  a = {n: rng.random(tuple(extent[::-1]), dtype=np.float32)
+       for n in stencil.input_names}
+  cells = 1
+  for e in extent:
+    cells *= e
+  t0 = time.time()
+  orc.run(a, iterate=2)
+  probe = (time.time() - t0) / 2
+  iters = int(max(2, min(40, target_seconds / max(probe, 1e-6))))
+  t0 = time.time()
+  orc.run(a, iterate=iters)
+  dt = time.time() - t0
+  return {
+      'value': cells * iters / dt, 'unit': 'cells*iters/s', 'cores': cores,
+      'kind': 'port',
+      'sample': '%s %s, iterate=%d (%.1f s), gcc -O2 -ffp-contract=off '
+                '-fopenmp, %d threads' % (stencil.app_name,
+                                          'x'.join(map(str, extent)), iters,
+                                          dt, cores),
+  }
+
+
+def main():
+  args = parse_args()
+  import torch
+  from soda_amd import core, dist as sdist, runtime
+  from soda_amd.codegen.hip import lower
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('--gpus %d needs torchrun --nproc-per-node %d' %
+                       (args.gpus, args.gpus))
+    raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  tdist = None
+  if world > 1:
+    import torch.distributed as tdist
+    tdist.init_process_group('nccl', device_id=dev)
+
+  stencil = core.from_file(args.soda, iterate=args.iterate)
+  extent = list(args.extent)
+  if args.scaling == 'weak' and world > 1:
+    extent[-1] *= world
+  ex = args.exchange_every
+  if args.fuse > 1:
+    ex = max(args.fuse, ex // args.fuse * args.fuse)
+  slab = sdist.Slab(stencil, extent, world, rank, ex)
+  local_extent = slab.local_extent
+
+  def options(fuse):
+    return lower.LowerOptions(strategy=args.strategy,
+                              fuse=(fuse,) if fuse > 1 else (),
+                              chunk_rows=args.chunk_rows,
+                              prefetch=args.prefetch, waves_x=args.waves_x,
+                              waves_y=args.waves_y)
+
+  prog = runtime.Program(stencil, options(args.fuse), device=local_rank,
+                         extent=local_extent)
+  stream = torch.cuda.current_stream().cuda_stream
+
+  # synthetic input: the same seeded global field on every rank, sliced
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234)
+  shape = tuple(extent[::-1])
+  np_dtypes = {'float32': torch.float32, 'float64': torch.float64,
+               'uint16': torch.int16, 'int16': torch.int16,
+               'int32': torch.int32}
+  a_bufs, b_bufs = [], []
+  for name, t in zip(stencil.input_names, stencil.input_types):
+    dt = np_dtypes[t.np_name]
+    if dt.is_floating_point:
+      full = torch.rand(shape, generator=gen, device=dev, dtype=dt)
+    else:
+      full = torch.randint(0, 30000, shape, generator=gen, device=dev,
+                           dtype=dt)
+    a_bufs.append(full[slab.begin:slab.end].clone())
+    del full
+    b_bufs.append(torch.empty_like(a_bufs[-1]))
+  torch.cuda.synchronize()
+
+  def step_fn(dst, src, lext, iters):
+    prog.run_device([t.data_ptr() for t in dst], [t.data_ptr() for t in src],
+                    lext, iterate=iters, stream=stream)
+
+  def one_step():
+    # a step always starts from the same buffers; ghosts of a_bufs are fresh
+    return sdist.run(slab, a_bufs, b_bufs, step_fn, args.iterate, tdist)
+
+  def barrier():
+    if world > 1:
+      tdist.barrier()
+
+  for _ in range(args.warmup):
+    one_step()
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    one_step()
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  cells = 1
+  for e in extent:
+    cells *= e
+  value = cells * args.iterate * args.steps / elapsed
+
+  # ---- roofline of the dominant kernel (rank 0's slab), HIP events ---------
+  table = stencil.symbol_table
+  bytes_cell = (sum(table[n].size_in_bytes for n in stencil.input_names) +
+                sum(table[n].size_in_bytes for n in stencil.output_names))
+  local_cells = 1
+  for e in local_extent:
+    local_cells *= e
+  fuse = max(1, args.fuse)
+
+  def dominant():
+    step_fn(b_bufs, a_bufs, local_extent, fuse)
+
+  dominant()
+  torch.cuda.synchronize()
+  reps = 50
+  kernel_ms = time_events(dominant, stream, reps)
+  passes = [p for p in prog.module.sorted_passes() if p.fused_iters == fuse]
+  kname = prog.module.kernels[passes[0].kernels[0]].name if passes else '?'
+  alg_bytes = float(local_cells) * bytes_cell
+  achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+  roofline = {
+      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+      'kernel': kname, 'kernel_ms': kernel_ms,
+      'algorithmic_bytes_per_launch': alg_bytes,
+      'iterations_per_launch': fuse,
+      'effective_GBs_at_8B_per_cell_iter': achieved * fuse,
+      'timing': 'hipEvent pair around %d back-to-back launches on the launch '
+                'stream' % reps,
+  }
+  traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
+  if os.path.exists(traffic_file):
+    try:
+      with open(traffic_file) as f:
+        measured = json.load(f)
+      if kname in measured:
+        roofline['traffic'] = measured[kname]['hbm_bytes_per_launch']
+        roofline['traffic_source'] = measured[kname].get('source')
+    except (OSError, ValueError, KeyError):
+      pass
+
+  result = {
+      'metric': 'stencil cells*iters/s, %s %s iterate=%d' %
+                (stencil.app_name, 'x'.join(map(str, extent)), args.iterate),
+      'value': value, 'unit': 'cells*iters/s', 'n_gpus': world,
+      'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+      'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
+      'data': 'synthetic',
+      'config': {
+          'workload': '%s %s %s iterate=%d' %
+                      (stencil.app_name,
+                       str(table[stencil.input_names[0]]),
+                       'x'.join(map(str, extent)), args.iterate),
+          'kernel_family': passes[0].kind if passes else '?',
+          'fused_iterations_per_launch': fuse,
+          'decomposition': 'slabs along dim %d, halo exchange every %d iters'
+                           % (stencil.dim - 1, ex) if world > 1 else 'none',
+          'launches_per_step': prog.last_launches()[0],
+      },
+      'roofline': roofline,
+  }
+
+  if world == 1 and rank == 0:
+    if not args.no_single_iter and fuse > 1:
+      prog1 = runtime.Program(stencil, options(1), device=local_rank,
+                              extent=local_extent)
+
+      def single():
+        prog1.run_device([t.data_ptr() for t in b_bufs],
+                         [t.data_ptr() for t in a_bufs], local_extent,
+                         iterate=args.iterate, stream=stream)
+
+      single()
+      torch.cuda.synchronize()
+      ms = time_events(single, stream, 3)
+      k1 = alg_bytes / (ms / args.iterate * 1e-3) / 1e9
+      result['single_iter'] = {
+          'value': cells * args.iterate / (ms * 1e-3),
+          'unit': 'cells*iters/s', 'ms_per_step': ms,
+          'kernel': prog1.module.kernels[0].name,
+          'roofline': {'bound': 'hbm', 'achieved': k1, 'peak': HBM_PEAK_GBS,
+                       'unit': 'GB/s', 'frac': k1 / HBM_PEAK_GBS},
+      }
+      prog1.close()
+    if not args.no_cpu_baseline:
+      result['cpu_baseline'] = cpu_baseline(stencil, extent, args.cpu_seconds)
+
+  if rank == 0:
+    print(json.dumps(result))
+  if world > 1:
+    tdist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

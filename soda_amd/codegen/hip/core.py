@@ -1,0 +1,110 @@
+"""The HIP backend's plug-in surface: `add_arguments` + `print_code`.
+
+Every backend of the reference is a module with exactly these two functions,
+registered and invoked by the driver (reference src/soda/sodac.py:99-102,
+198-200; src/soda/codegen/frt/core.py:10-27; src/soda/codegen/xilinx/
+opencl.py:55-142).  This module slots into the same place:
+
+  --hip-kernel FILE   print the generated HIP source ('-' = stdout), the
+                      counterpart of --xocl-kernel;
+  --hip-backend       JIT-build the kernels for gfx950 and RUN the program on
+                      the GPU with the reference harness's inputs, checking
+                      nothing by itself (the oracle lives in tests/); prints
+                      one JSON line with timing.
+"""
+import argparse
+import json
+import shutil
+import sys
+import tempfile
+import time
+
+from soda_amd import core, util
+from soda_amd.codegen.hip import lower
+
+
+def add_arguments(parser) -> None:
+  parser.add_argument('--hip-kernel', type=str, dest='hip_kernel',
+                      metavar='file', help='HIP kernel code for gfx950')
+  parser.add_argument('--hip-backend', action='store_true', dest='hip_backend',
+                      help='JIT-build the HIP kernels and run them on the GPU')
+  parser.add_argument('--hip-strategy', type=str, dest='hip_strategy',
+                      choices=('auto', 'direct', 'march'), default='auto',
+                      help='kernel family: register-marching wavefront strips '
+                      '(2-D programs) or one cell per thread')
+  parser.add_argument('--hip-fuse', type=int, nargs='*', dest='hip_fuse',
+                      metavar='T', default=[4],
+                      help='temporal blocking: iterations fused per launch')
+  parser.add_argument('--hip-vec', type=int, dest='hip_vec', metavar='V',
+                      help='cells per lane per row (default: 16 bytes worth)')
+  parser.add_argument('--hip-chunk-rows', type=int, dest='hip_chunk_rows',
+                      default=64, help='rows one wavefront marches over')
+  parser.add_argument('--hip-prefetch', type=int, dest='hip_prefetch',
+                      default=2, help='input rows loaded ahead of use')
+  parser.add_argument('--hip-extent', type=int, nargs='+', dest='hip_extent',
+                      metavar='N', help='grid size for --hip-backend')
+  parser.add_argument('--hip-device', type=int, dest='hip_device', default=0)
+
+
+def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
+  return lower.LowerOptions(strategy=args.hip_strategy,
+                            fuse=tuple(args.hip_fuse or ()),
+                            vec=args.hip_vec,
+                            chunk_rows=args.hip_chunk_rows,
+                            prefetch=args.hip_prefetch)
+
+
+def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
+  if args.hip_kernel is not None:
+    opts = options_from_args(args)
+    if opts.vec is None:
+      opts.vec = lower.default_vec(stencil)
+    with tempfile.TemporaryFile(mode='w+') as tmp:
+      tmp.write(lower.lower(stencil, opts).source)
+      tmp.seek(0)
+      if args.hip_kernel == '-':
+        shutil.copyfileobj(tmp, sys.stdout)
+      else:
+        with open(args.hip_kernel, 'w') as f:
+          shutil.copyfileobj(tmp, f)
+  if args.hip_backend:
+    run(stencil, args)
+
+
+def default_extent(stencil: core.Stencil):
+  """The reference harness's default problem size: tile sizes, and one more
+  than the stencil's height in the streamed dimension (frt/host.py:454-461)."""
+  dims = list(stencil.tile_size[:-1])
+  dims.append(stencil.stencil_dim[-1] + 1)
+  return dims
+
+
+def run(stencil: core.Stencil, args: argparse.Namespace) -> None:
+  import numpy as np
+  from soda_amd import runtime
+  extent = list(args.hip_extent or default_extent(stencil))
+  if len(extent) != stencil.dim:
+    raise util.InputError('--hip-extent needs %d values' % stencil.dim)
+  shape = tuple(extent[::-1])
+  rng = np.random.default_rng(0)
+  inputs = {}
+  for name, t in zip(stencil.input_names, stencil.input_types):
+    if t.is_float:
+      inputs[name] = rng.random(shape, dtype=np.float64).astype(t.np_name)
+    else:  # p + q (+ r): the reference harness's integer init
+      grids = np.indices(shape).sum(axis=0)
+      inputs[name] = grids.astype(t.np_name)
+  prog = runtime.Program(stencil, options_from_args(args),
+                         device=args.hip_device, extent=extent)
+  t0 = time.time()
+  outputs = prog.run(inputs)
+  seconds = time.time() - t0
+  cells = float(np.prod(extent)) * stencil.iterate
+  print(json.dumps({
+      'kernel': stencil.app_name, 'extent': extent,
+      'iterate': stencil.iterate, 'seconds_incl_copies': seconds,
+      'cells_iters_per_s_incl_copies': cells / seconds,
+      'kernels': [k.name for k in prog.module.kernels],
+      'checksum': {n: float(np.asarray(v, dtype=np.float64).sum())
+                   for n, v in outputs.items()},
+  }))

@@ -1,0 +1,147 @@
+// soda_rt.h -- device-side runtime of the generated gfx950 stencil kernels.
+//
+// The code generator (soda_amd/codegen/hip) pastes this text in front of every
+// program's kernels before JIT compilation (hiprtc has no include path into
+// this tree).  It plays the part of the fixed helper text the reference's HLS
+// emitter prints ahead of its modules (reference
+// src/soda/codegen/xilinx/hls_kernel.py:238-336: BurstRead/BurstWrite,
+// ReadData/WriteData): moving rows between memory and on-chip storage.  Here
+// "on-chip" is the register file of a 64-lane wavefront; neighbours along
+// dimension 0 come from adjacent lanes through DPP whole-wave shifts instead
+// of the FPGA's FIFO-chained line buffer.
+//
+// gfx950 only: wave64, DPP wave_shr/wave_shl (GFX9 encodings).
+
+typedef __INT8_TYPE__ int8_t;
+typedef __UINT8_TYPE__ uint8_t;
+typedef __INT16_TYPE__ int16_t;
+typedef __UINT16_TYPE__ uint16_t;
+typedef __INT32_TYPE__ int32_t;
+typedef __UINT32_TYPE__ uint32_t;
+typedef __INT64_TYPE__ int64_t;
+typedef __UINT64_TYPE__ uint64_t;
+
+// must match soda_hip_kargs_t in include/soda_hip.h
+struct soda_hip_kargs_t {
+  void* buf[16];
+  int64_t stride[4];
+  int32_t extent[4];
+  int32_t ntile[4];
+};
+
+#define SODA_DEV static __device__ __forceinline__
+
+// min/max/abs of the DSL: arguments evaluated once, result type given by the
+// usual arithmetic conversions (same as the CPU oracle's macros in ir.py)
+template <class A, class B>
+SODA_DEV auto soda_min(A a, B b) -> decltype(a + b) {
+  const decltype(a + b) x = a, y = b;
+  return y < x ? y : x;
+}
+template <class A, class B>
+SODA_DEV auto soda_max(A a, B b) -> decltype(a + b) {
+  const decltype(a + b) x = a, y = b;
+  return x < y ? y : x;
+}
+template <class A>
+SODA_DEV auto soda_abs(A a) -> decltype(+a) {
+  const decltype(+a) x = a;
+  return x < 0 ? -x : x;
+}
+#define SODA_MIN(a, b) soda_min((a), (b))
+#define SODA_MAX(a, b) soda_max((a), (b))
+#define SODA_ABS(a) soda_abs((a))
+
+// ---- whole-wave lane shifts (DPP) -----------------------------------------
+// soda_lane_dn(v): lane i receives lane i-1's v (lane 0 receives 0).
+// soda_lane_up(v): lane i receives lane i+1's v (lane 63 receives 0).
+SODA_DEV int soda_dpp_shr1(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf,
+                                     false);
+}
+SODA_DEV int soda_dpp_shl1(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf,
+                                     false);
+}
+
+template <class T, int kSize = sizeof(T)>
+struct soda_lane_shift;
+
+template <class T>
+struct soda_lane_shift<T, 4> {
+  SODA_DEV T dn(T v) {
+    return __builtin_bit_cast(T, soda_dpp_shr1(__builtin_bit_cast(int, v)));
+  }
+  SODA_DEV T up(T v) {
+    return __builtin_bit_cast(T, soda_dpp_shl1(__builtin_bit_cast(int, v)));
+  }
+};
+
+template <class T>
+struct soda_lane_shift<T, 8> {
+  struct pair { int lo, hi; };
+  SODA_DEV T dn(T v) {
+    pair p = __builtin_bit_cast(pair, v);
+    p.lo = soda_dpp_shr1(p.lo);
+    p.hi = soda_dpp_shr1(p.hi);
+    return __builtin_bit_cast(T, p);
+  }
+  SODA_DEV T up(T v) {
+    pair p = __builtin_bit_cast(pair, v);
+    p.lo = soda_dpp_shl1(p.lo);
+    p.hi = soda_dpp_shl1(p.hi);
+    return __builtin_bit_cast(T, p);
+  }
+};
+
+template <class T>
+struct soda_lane_shift<T, 2> {  // widened: one VGPR per element
+  SODA_DEV T dn(T v) { return (T)soda_dpp_shr1((int)v); }
+  SODA_DEV T up(T v) { return (T)soda_dpp_shl1((int)v); }
+};
+
+template <class T>
+struct soda_lane_shift<T, 1> {
+  SODA_DEV T dn(T v) { return (T)soda_dpp_shr1((int)v); }
+  SODA_DEV T up(T v) { return (T)soda_dpp_shl1((int)v); }
+};
+
+template <class T> SODA_DEV T soda_lane_dn(T v) { return soda_lane_shift<T>::dn(v); }
+template <class T> SODA_DEV T soda_lane_up(T v) { return soda_lane_shift<T>::up(v); }
+
+// ---- row fragments: V consecutive cells of one row per lane ----------------
+template <class T, int V>
+struct soda_vec {
+  typedef T type __attribute__((ext_vector_type(V)));
+};
+
+template <class T, int V>
+SODA_DEV void soda_load_frag(T (&dst)[V], const T* __restrict__ p) {
+  if constexpr (V == 1) {
+    dst[0] = *p;
+  } else {
+    typedef typename soda_vec<T, V>::type vec_t;
+    const vec_t t = *reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+    for (int e = 0; e < V; ++e) dst[e] = t[e];
+  }
+}
+
+template <class T, int V>
+SODA_DEV void soda_zero_frag(T (&dst)[V]) {
+#pragma unroll
+  for (int e = 0; e < V; ++e) dst[e] = (T)0;
+}
+
+template <class T, int V>
+SODA_DEV void soda_store_frag(T* __restrict__ p, const T (&src)[V]) {
+  if constexpr (V == 1) {
+    *p = src[0];
+  } else {
+    typedef typename soda_vec<T, V>::type vec_t;
+    vec_t t;
+#pragma unroll
+    for (int e = 0; e < V; ++e) t[e] = src[e];
+    *reinterpret_cast<vec_t*>(p) = t;
+  }
+}

@@ -1,0 +1,124 @@
+"""Multi-GPU execution: slab decomposition + halo exchange, one process per GPU.
+
+The reference has no multi-device support at all (its only
+scale-out is tiling with a replicated halo done by the generated host,
+reference src/soda/codegen/frt/host.py:124-128,181-249, and cyclic interleave
+over <= 4 DRAM banks, docs/data-layout.md:62-127).  This is the MI355X-native
+counterpart of that host-side tiling: the LAST dimension -- the one SODA streams
+-- is cut into one contiguous slab per GPU, and what the FPGA host replicates
+once (the halo between tiles) is exchanged between neighbours as the iterations
+advance.
+
+Communication-avoiding schedule: xGMI P2P messages of a few hundred KiB are
+latency-bound, so instead of one exchange per iteration every rank keeps
+`K * radius` ghost rows per side, runs K iterations with no communication
+(ghost rows decay from the outside in, own rows stay exact), then refreshes
+the ghosts with ONE send/recv pair per neighbour.  No reduction collective
+exists anywhere on the path.  The result on the global valid box is bit-for-bit
+the single-GPU result: every cell runs the same arithmetic.
+
+The local compute engine is injected (`step(dst, src, local_extent, iters)`):
+on GPUs it is `runtime.Program.run_device`; the CPU tests drive the same
+decomposition/exchange code over gloo with a CPU engine.
+"""
+from typing import Callable, List, Optional, Sequence, Tuple
+
+from soda_amd import core, util
+
+
+class Slab:
+  """Geometry of one rank's share of the grid along the last dimension."""
+
+  def __init__(self, stencil: core.Stencil, extent: Sequence[int], world: int,
+               rank: int, exchange_every: int):
+    if world < 1 or not 0 <= rank < world:
+      raise util.InputError('bad rank %d of %d' % (rank, world))
+    if exchange_every < 1:
+      raise util.InputError('exchange_every must be >= 1')
+    self.stencil = stencil
+    self.extent = tuple(extent)
+    self.world = world
+    self.rank = rank
+    self.exchange_every = exchange_every
+    n = self.extent[-1]
+    lo, hi = stencil.radius
+    self.reach_lo = -lo[-1]          # rows an iteration reads below a cell
+    self.reach_hi = hi[-1]           # ... and above
+    self.ghost_lo = self.reach_lo * exchange_every if rank > 0 else 0
+    self.ghost_hi = self.reach_hi * exchange_every if rank < world - 1 else 0
+    # own rows: as even as possible, first ranks take the remainder
+    base, extra = divmod(n, world)
+    self.own_begin = rank * base + min(rank, extra)
+    self.own_rows = base + (1 if rank < extra else 0)
+    self.own_end = self.own_begin + self.own_rows
+    need = max(self.reach_lo, self.reach_hi) * exchange_every
+    if world > 1 and self.own_rows < need:
+      raise util.InputError(
+          'slab of %d rows is thinner than the %d-row halo; use fewer GPUs or '
+          'a smaller exchange interval' % (self.own_rows, need))
+    self.begin = self.own_begin - self.ghost_lo   # first global row held
+    self.end = self.own_end + self.ghost_hi
+    self.rows = self.end - self.begin
+    self.local_extent = self.extent[:-1] + (self.rows,)
+    self.row_cells = 1
+    for e in self.extent[:-1]:
+      self.row_cells *= e
+
+  # neighbour traffic, in local row indices: (peer, send rows, recv rows)
+  def messages(self) -> List[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
+    out = []
+    k = self.exchange_every
+    if self.rank > 0:
+      # lower neighbour needs my first own rows as ITS upper ghosts
+      send = (self.ghost_lo, self.ghost_lo + self.reach_hi * k)
+      recv = (0, self.ghost_lo)
+      out.append((self.rank - 1, send, recv))
+    if self.rank < self.world - 1:
+      top = self.ghost_lo + self.own_rows
+      send = (top - self.reach_lo * k, top)
+      recv = (top, top + self.ghost_hi)
+      out.append((self.rank + 1, send, recv))
+    return out
+
+
+def exchange(slab: Slab, tensors: Sequence, dist_module, group=None) -> None:
+  """Refreshes the ghost rows of every tensor (torch tensors whose first axis
+  is the last DSL dimension) from the neighbours' own rows.  One batched
+  isend/irecv per call; blocks until the receives have landed."""
+  if slab.world == 1:
+    return
+  ops = []
+  for t in tensors:
+    for peer, (s0, s1), (r0, r1) in slab.messages():
+      if s1 > s0:
+        ops.append(dist_module.P2POp(dist_module.isend, t[s0:s1], peer, group))
+      if r1 > r0:
+        ops.append(dist_module.P2POp(dist_module.irecv, t[r0:r1], peer, group))
+  if ops:
+    for req in dist_module.batch_isend_irecv(ops):
+      req.wait()
+
+
+def run(slab: Slab, bufs_a: Sequence, bufs_b: Sequence,
+        step: Callable[[Sequence, Sequence, Tuple[int, ...], int], None],
+        iterate: int, dist_module, group=None, ghosts_fresh: bool = True):
+  """Advances the program `iterate` iterations.  `bufs_a` hold the current
+  state (own rows + ghosts), `bufs_b` are same-shaped work arrays; returns the
+  list that holds the result.  `ghosts_fresh`: ghosts of `bufs_a` already hold
+  neighbour data (true right after slicing them out of the global input)."""
+  cur, nxt = list(bufs_a), list(bufs_b)
+  done = 0
+  fresh = ghosts_fresh
+  while done < iterate:
+    k = min(slab.exchange_every, iterate - done)
+    if not fresh:
+      exchange(slab, cur, dist_module, group)
+    step(nxt, cur, slab.local_extent, k)
+    cur, nxt = nxt, cur
+    done += k
+    fresh = False
+  return cur
+
+
+def rounds(iterate: int, exchange_every: int) -> int:
+  return -(-iterate // exchange_every)

@@ -509,7 +509,13 @@ def c_expr(node: Node,
 
 
 C_PRELUDE = '''\
-#define SODA_MIN(a, b) ((b) < (a) ? (b) : (a))
-#define SODA_MAX(a, b) ((a) < (b) ? (b) : (a))
-#define SODA_ABS(a) ((a) < 0 ? -(a) : (a))
+/* each argument appears ONCE in the expansion (a nested 19-way min() must not
+ * blow up textually) and is evaluated once; the result type is that of the
+ * conditional operator, i.e. the usual arithmetic conversions */
+#define SODA_MIN(a, b) ({ __auto_type soda_a_ = (a); __auto_type soda_b_ = (b); \\
+                          soda_b_ < soda_a_ ? soda_b_ : soda_a_; })
+#define SODA_MAX(a, b) ({ __auto_type soda_a_ = (a); __auto_type soda_b_ = (b); \\
+                          soda_a_ < soda_b_ ? soda_b_ : soda_a_; })
+#define SODA_ABS(a) ({ __auto_type soda_a_ = (a); \\
+                       soda_a_ < 0 ? -soda_a_ : soda_a_; })
 '''

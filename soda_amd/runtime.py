@@ -1,0 +1,419 @@
+"""ctypes binding of libsoda_hip.so and the JIT driver on top of it.
+
+The Python side of the drop-in boundary (include/soda_hip.h).  The reference's
+host reaches its kernel either linked directly or through the FRT runtime
+(`fpga::Instance(bitstream)`, SetArg/WriteToDevice/Exec/ReadFromDevice/Finish;
+reference src/soda/codegen/frt/host.py:97-113,288-322).  `Program` is that
+object for a GPU: built from HIP source text instead of a bitstream, it owns
+the loaded code object and runs it on host or device arrays.
+
+There is no CPU fallback: a missing library, a failed JIT or a missing GPU
+raises `util.BackendError`.
+"""
+import ctypes
+import hashlib
+import os
+from typing import Dict, Optional, Sequence
+
+from soda_amd import core, util
+from soda_amd.codegen.hip import lower
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsoda_hip.so')
+CACHE_DIR = os.environ.get('SODA_HIP_CACHE',
+                           os.path.join(_HERE, '_jit_cache'))
+ARCH = 'gfx950'
+COMPILE_OPTIONS = ('--offload-arch=%s' % ARCH, '-O3', '-ffp-contract=off',
+                   '-std=c++17')
+
+MAX_DIM = 4
+MAX_TENSORS = 16
+MAX_KERNELS = 32
+MAX_PASSES = 8
+MAX_PASS_KERNELS = 16
+NAME_LEN = 64
+ABI_VERSION = 1
+
+
+class KernelDesc(ctypes.Structure):
+  _fields_ = [('name', ctypes.c_char * NAME_LEN),
+              ('block', ctypes.c_int32 * 3),
+              ('tile', ctypes.c_int32 * MAX_DIM),
+              ('lds_bytes', ctypes.c_int32),
+              ('reserved', ctypes.c_int32)]
+
+
+class PassDesc(ctypes.Structure):
+  _fields_ = [('fused_iters', ctypes.c_int32),
+              ('num_kernels', ctypes.c_int32),
+              ('kernel', ctypes.c_int32 * MAX_PASS_KERNELS)]
+
+
+class Plan(ctypes.Structure):
+  _fields_ = [('abi_version', ctypes.c_int32), ('dim', ctypes.c_int32),
+              ('num_inputs', ctypes.c_int32), ('num_outputs', ctypes.c_int32),
+              ('num_locals', ctypes.c_int32),
+              ('elem_size', ctypes.c_int32 * MAX_TENSORS),
+              ('num_kernels', ctypes.c_int32),
+              ('kernels', KernelDesc * MAX_KERNELS),
+              ('num_passes', ctypes.c_int32),
+              ('passes', PassDesc * MAX_PASSES)]
+
+
+class HostTensor(ctypes.Structure):
+  _fields_ = [('ptr', ctypes.c_void_p),
+              ('extent', ctypes.POINTER(ctypes.c_int32)),
+              ('stride', ctypes.POINTER(ctypes.c_int32)),
+              ('min', ctypes.POINTER(ctypes.c_int32))]
+
+
+# every symbol include/soda_hip.h declares: name -> (restype, argtypes)
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_pvp = ctypes.POINTER(ctypes.c_void_p)
+_pi32 = ctypes.POINTER(ctypes.c_int32)
+API = {
+    'soda_hip_abi_version': (ctypes.c_int, []),
+    'soda_hip_status_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'soda_hip_last_error': (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
+    'soda_hip_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'soda_hip_compile': (ctypes.c_int, [
+        ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), _i32,
+        _pvp, ctypes.POINTER(ctypes.c_size_t)
+    ]),
+    'soda_hip_free_code': (None, [_vp]),
+    'soda_hip_program_create': (ctypes.c_int, [
+        _vp, ctypes.c_size_t, ctypes.POINTER(Plan), _i32, _pvp
+    ]),
+    'soda_hip_program_destroy': (ctypes.c_int, [_vp]),
+    'soda_hip_run_device': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _i32, _vp]),
+    'soda_hip_run_host': (ctypes.c_int, [
+        _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32
+    ]),
+    'soda_hip_run_host_box': (ctypes.c_int, [
+        _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32,
+        _pi32, _pi32
+    ]),
+    'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),
+    'soda_hip_malloc': (ctypes.c_int, [_i32, ctypes.c_size_t, _pvp]),
+    'soda_hip_free': (ctypes.c_int, [_i32, _vp]),
+    'soda_hip_memcpy_h2d': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
+    'soda_hip_memcpy_d2h': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
+    'soda_hip_memset': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_size_t, _vp]),
+    'soda_hip_stream_synchronize': (ctypes.c_int, [_vp]),
+    'soda_hip_event_create': (ctypes.c_int, [_pvp]),
+    'soda_hip_event_record': (ctypes.c_int, [_vp, _vp]),
+    'soda_hip_event_elapsed_ms': (ctypes.c_int, [
+        _vp, _vp, ctypes.POINTER(ctypes.c_float)
+    ]),
+    'soda_hip_event_destroy': (ctypes.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def library() -> ctypes.CDLL:
+  """Loads libsoda_hip.so once; fails loudly if it was not built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise util.BackendError(
+          '%s is missing: build it with `python -c "import __graft_entry__ as '
+          'g; g.build()"` (hipcc). There is no CPU fallback.' % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+    # libamdhip64/libhiprtc (same SONAMEs as /opt/rocm's).  Two copies in one
+    # process cannot both open the GPU, so when torch is installed it is
+    # loaded FIRST and libsoda_hip.so binds to the copy torch brought in.
+    if not os.environ.get('SODA_HIP_NO_TORCH'):
+      try:
+        import torch  # noqa: F401
+      except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in API.items():
+      fn = getattr(lib, name)
+      fn.restype = restype
+      fn.argtypes = argtypes
+    if lib.soda_hip_abi_version() != ABI_VERSION:
+      raise util.BackendError('libsoda_hip.so has ABI version %d, expected %d' %
+                              (lib.soda_hip_abi_version(), ABI_VERSION))
+    _lib = lib
+  return _lib
+
+
+def last_error() -> str:
+  lib = library()
+  n = lib.soda_hip_last_error(None, 0)
+  buf = ctypes.create_string_buffer(n + 1)
+  lib.soda_hip_last_error(buf, n + 1)
+  return buf.value.decode(errors='replace')
+
+
+def check(status: int, what: str) -> None:
+  if status != 0:
+    lib = library()
+    raise util.BackendError(
+        '%s: %s: %s' % (what, lib.soda_hip_status_string(status).decode(),
+                        last_error()))
+
+
+def device_count() -> int:
+  n = ctypes.c_int(0)
+  if library().soda_hip_device_count(ctypes.byref(n)) != 0:
+    return 0
+  return n.value
+
+
+def compile_source(source: str, name: str = 'soda.hip',
+                   options: Sequence[str] = COMPILE_OPTIONS,
+                   cache_dir: Optional[str] = None) -> bytes:
+  """HIP text -> gfx950 code object, cached on disk by content hash.  Runs
+  without a GPU (hiprtc), so `build()` can pre-compile on the CPU box."""
+  cache_dir = CACHE_DIR if cache_dir is None else cache_dir
+  key = hashlib.sha256(
+      ('\0'.join(options) + '\0' + source).encode()).hexdigest()[:24]
+  path = os.path.join(cache_dir, '%s_%s.hsaco' % (name.replace('.', '_'), key))
+  if os.path.exists(path):
+    with open(path, 'rb') as f:
+      return f.read()
+  lib = library()
+  opts = [o.encode() for o in options]
+  arr = (ctypes.c_char_p * len(opts))(*opts)
+  code = ctypes.c_void_p()
+  size = ctypes.c_size_t()
+  check(
+      lib.soda_hip_compile(source.encode(), name.encode(), arr, len(opts),
+                           ctypes.byref(code), ctypes.byref(size)),
+      'JIT of %s' % name)
+  try:
+    blob = ctypes.string_at(code, size.value)
+  finally:
+    lib.soda_hip_free_code(code)
+  try:
+    os.makedirs(cache_dir, exist_ok=True)
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    with open(tmp, 'wb') as f:
+      f.write(blob)
+    os.replace(tmp, path)
+  except OSError:
+    pass  # read-only tree: run uncached
+  return blob
+
+
+def make_plan(mod: lower.Module) -> Plan:
+  st = mod.stencil
+  plan = Plan()
+  plan.abi_version = ABI_VERSION
+  plan.dim = st.dim
+  plan.num_inputs = len(st.input_names)
+  plan.num_outputs = len(st.output_names)
+  plan.num_locals = len(st.local_names)
+  if len(mod.elem_size) > MAX_TENSORS:
+    raise util.SemanticError('more than %d tensors' % MAX_TENSORS)
+  for i, s in enumerate(mod.elem_size):
+    plan.elem_size[i] = s
+  if len(mod.kernels) > MAX_KERNELS:
+    raise util.SemanticError('more than %d kernels' % MAX_KERNELS)
+  plan.num_kernels = len(mod.kernels)
+  for i, k in enumerate(mod.kernels):
+    if len(k.name) >= NAME_LEN:
+      raise util.SemanticError('kernel name too long: %s' % k.name)
+    plan.kernels[i].name = k.name.encode()
+    for d in range(3):
+      plan.kernels[i].block[d] = k.block[d]
+    for d in range(MAX_DIM):
+      plan.kernels[i].tile[d] = k.tile[d]
+    plan.kernels[i].lds_bytes = k.lds_bytes
+  passes = mod.sorted_passes()
+  if len(passes) > MAX_PASSES:
+    raise util.SemanticError('more than %d passes' % MAX_PASSES)
+  plan.num_passes = len(passes)
+  for i, p in enumerate(passes):
+    plan.passes[i].fused_iters = p.fused_iters
+    if len(p.kernels) > MAX_PASS_KERNELS:
+      raise util.SemanticError(
+          'a pass of %d kernels exceeds the limit of %d' %
+          (len(p.kernels), MAX_PASS_KERNELS))
+    plan.passes[i].num_kernels = len(p.kernels)
+    for j, k in enumerate(p.kernels):
+      plan.passes[i].kernel[j] = k
+  return plan
+
+
+def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
+  """Cells per lane per row: 16 bytes' worth, reduced until it divides the
+  row length (rows must stay 16-byte aligned for the vector loads)."""
+  vec = lower.default_vec(stencil)
+  if extent is not None:
+    while vec > 1 and extent[0] % vec:
+      vec //= 2
+  return vec
+
+
+class Program:
+  """A SODA program JIT-built for gfx950 and loaded on one GPU."""
+
+  def __init__(self, stencil: core.Stencil,
+               opts: Optional[lower.LowerOptions] = None, device: int = 0,
+               extent: Optional[Sequence[int]] = None):
+    self.stencil = stencil
+    self.opts = opts or lower.LowerOptions()
+    if self.opts.vec is None:
+      self.opts.vec = pick_vec(stencil, extent)
+    self.device = device
+    self.module = lower.lower(stencil, self.opts)
+    self.plan = make_plan(self.module)
+    self.code = compile_source(self.module.source,
+                               '%s.hip' % stencil.app_name)
+    self._lib = library()
+    self._handle = ctypes.c_void_p()
+    check(
+        self._lib.soda_hip_program_create(self.code, len(self.code),
+                                          ctypes.byref(self.plan), device,
+                                          ctypes.byref(self._handle)),
+        'loading `%s` on GPU %d' % (stencil.app_name, device))
+
+  # -- lifecycle -----------------------------------------------------------
+  def close(self) -> None:
+    if getattr(self, '_handle', None):
+      self._lib.soda_hip_program_destroy(self._handle)
+      self._handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  # -- checks shared by both entry points ----------------------------------
+  def _check_extent(self, extent: Sequence[int]) -> None:
+    if len(extent) != self.stencil.dim:
+      raise util.InputError('extent must have %d entries' % self.stencil.dim)
+    if self.opts.vec > 1 and extent[0] % self.opts.vec and any(
+        p.kind != 'direct' for p in self.module.passes):
+      raise util.InputError(
+          'this program was built for rows that are a multiple of %d cells; '
+          'rebuild it for extent %s' % (self.opts.vec, tuple(extent)))
+
+  # -- device-resident arrays (the <app>_kernel analogue) ------------------
+  def run_device(self, outputs: Sequence[int], inputs: Sequence[int],
+                 extent: Sequence[int], iterate: Optional[int] = None,
+                 stream: int = 0) -> None:
+    """`outputs` / `inputs` are device addresses (e.g. tensor.data_ptr()) of
+    dense dim-0-fastest arrays; asynchronous on `stream`."""
+    st = self.stencil
+    iterate = st.iterate if iterate is None else iterate
+    self._check_extent(extent)
+    if len(outputs) != len(st.output_names) or len(inputs) != len(
+        st.input_names):
+      raise util.InputError('wrong number of tensors')
+    outs = (ctypes.c_void_p * len(outputs))(*outputs)
+    ins = (ctypes.c_void_p * len(inputs))(*inputs)
+    ext = (ctypes.c_int32 * len(extent))(*extent)
+    check(
+        self._lib.soda_hip_run_device(self._handle, outs, ins, ext, iterate,
+                                      ctypes.c_void_p(stream)),
+        'running `%s`' % st.app_name)
+
+  def last_launches(self):
+    a, b = ctypes.c_int32(), ctypes.c_int32()
+    check(self._lib.soda_hip_last_launches(self._handle, ctypes.byref(a),
+                                           ctypes.byref(b)), 'last_launches')
+    return a.value, b.value
+
+  # -- host arrays (the soda::app::<app> analogue) -------------------------
+  def run(self, inputs: Dict[str, 'numpy.ndarray'],
+          iterate: Optional[int] = None,
+          outputs: Optional[Dict[str, 'numpy.ndarray']] = None
+          ) -> Dict[str, 'numpy.ndarray']:
+    """numpy in, numpy out.  Array shape is extent reversed (dim 0 fastest =
+    last axis).  Only the valid box of each output is written, the rest keeps
+    what the caller's array held (zeros for arrays allocated here)."""
+    import numpy as np
+    st = self.stencil
+    iterate = st.iterate if iterate is None else iterate
+    first = inputs[st.input_names[0]]
+    extent = tuple(first.shape[::-1])
+    self._check_extent(extent)
+    dim = st.dim
+    keep = []
+
+    def describe(arr, np_name):
+      if arr.dtype != np.dtype(np_name):
+        raise util.InputError('expected dtype %s, got %s' % (np_name, arr.dtype))
+      if arr.shape != first.shape:
+        raise util.InputError('all tensors must share one shape')
+      item = arr.dtype.itemsize
+      strides = [s // item for s in arr.strides[::-1]]
+      if any(s * item != b for s, b in zip(strides, arr.strides[::-1])):
+        raise util.InputError('strides must be whole elements')
+      ext = (ctypes.c_int32 * dim)(*extent)
+      strd = (ctypes.c_int32 * dim)(*strides)
+      mn = (ctypes.c_int32 * dim)(*([0] * dim))
+      keep.extend((ext, strd, mn, arr))
+      return HostTensor(arr.ctypes.data, ext, strd, mn)
+
+    ins = (HostTensor * len(st.input_names))(*[
+        describe(np.asarray(inputs[n]), t.np_name)
+        for n, t in zip(st.input_names, st.input_types)
+    ])
+    result = {}
+    for n, t in zip(st.output_names, st.output_types):
+      if outputs is not None and n in outputs:
+        result[n] = outputs[n]
+      else:
+        result[n] = np.zeros(first.shape, dtype=np.dtype(t.np_name))
+    outs = (HostTensor * len(st.output_names))(*[
+        describe(result[n], t.np_name)
+        for n, t in zip(st.output_names, st.output_types)
+    ])
+    lo, hi = [], []
+    for n in st.output_names:
+      l, h = st.valid_box(extent, n, iterate)
+      lo.extend(l)
+      hi.extend(max(a, b) for a, b in zip(h, l))
+    vlo = (ctypes.c_int32 * len(lo))(*lo)
+    vhi = (ctypes.c_int32 * len(hi))(*hi)
+    check(
+        self._lib.soda_hip_run_host_box(self._handle, ins, outs, iterate, vlo,
+                                        vhi), 'running `%s`' % st.app_name)
+    return result
+
+
+class Event:
+  """hipEvent wrapper; records on the stream the kernels are launched on."""
+
+  def __init__(self):
+    self._lib = library()
+    self._h = ctypes.c_void_p()
+    check(self._lib.soda_hip_event_create(ctypes.byref(self._h)),
+          'event_create')
+
+  def record(self, stream: int = 0) -> None:
+    check(self._lib.soda_hip_event_record(self._h, ctypes.c_void_p(stream)),
+          'event_record')
+
+  def elapsed_ms(self, stop: 'Event') -> float:
+    ms = ctypes.c_float()
+    check(self._lib.soda_hip_event_elapsed_ms(self._h, stop._h,
+                                              ctypes.byref(ms)),
+          'event_elapsed')
+    return ms.value
+
+  def __del__(self):
+    try:
+      if self._h:
+        self._lib.soda_hip_event_destroy(self._h)
+    except Exception:
+      pass
+
+
+def synchronize(stream: int = 0) -> None:
+  check(library().soda_hip_stream_synchronize(ctypes.c_void_p(stream)),
+        'stream_synchronize')

@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Integer programs must match bit for bit; floating-point programs are compiled
+with -ffp-contract=off from the same expression text as the oracle, so they
+are ALSO required to match bit for bit on the valid box (stricter than the
+reference harness's 1e-5 rule, frt/host.py:634-657, which is checked too).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import soda_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(stencil, extent, seed=0, kind='random'):
+  shape = tuple(extent[::-1])
+  rng = np.random.default_rng(seed)
+  out = {}
+  for name, t in zip(stencil.input_names, stencil.input_types):
+    dt = np.dtype(t.np_name)
+    if kind == 'ramp':  # the reference harness's integer init: p + q (+ r)
+      out[name] = np.indices(shape).sum(axis=0).astype(dt)
+    elif t.is_float:
+      out[name] = rng.random(shape, dtype=np.float64).astype(dt)
+    else:
+      info = np.iinfo(dt)
+      out[name] = rng.integers(info.min, int(info.max) + 1, size=shape,
+                               dtype=np.int64).astype(dt)
+  return out
+
+
+def _check(stencil, extent, opts, iterate=None, seed=0, kind='random',
+           oracle='numpy'):
+  from soda_amd import runtime
+  from oracle import numpy_oracle, c_oracle
+  inputs = _inputs(stencil, extent, seed, kind)
+  iterate = stencil.iterate if iterate is None else iterate
+  with runtime.Program(stencil, opts, extent=extent) as prog:
+    got = prog.run(inputs, iterate=iterate)
+    kernels = [k.name for k in prog.module.kernels]
+  if oracle == 'numpy':
+    want = numpy_oracle.run(stencil, inputs, iterate=iterate)
+  else:
+    want = c_oracle.COracle(stencil).run(inputs, iterate=iterate)
+  for name in stencil.output_names:
+    lo, hi = stencil.valid_box(extent, name, iterate)
+    assert all(h > l for l, h in zip(lo, hi)), 'empty valid box: bad test'
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    g, w = got[name][idx], want[name][idx]
+    assert numpy_oracle.compare(got[name], want[name], lo, hi) == 0
+    same = g.view(np.uint8) == w.view(np.uint8) if g.dtype.kind == 'f' \
+        else g == w
+    assert same.all(), '%s: %d cells not bit-identical (kernels %s)' % (
+        name, (~same).sum(), kernels)
+    # outside the box the caller's array is untouched (zeros here)
+    mask = np.ones(got[name].shape, bool)
+    mask[idx] = False
+    assert not got[name][mask].any()
+
+
+def test_dpp_wave_shift_direction(built):
+  """soda_lane_dn/up move data the way lower.py assumes."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  src = lower.runtime_text() + '''
+extern "C" __global__ void probe(soda_hip_kargs_t a) {
+  int* out = (int*)a.buf[1];
+  const int lane = threadIdx.x;
+  out[lane] = soda_lane_dn(lane + 100);
+  out[64 + lane] = soda_lane_up(lane + 100);
+  out[128 + lane] = (int)soda_lane_dn((uint16_t)(lane + 7));
+  out[192 + lane] = (int)(soda_lane_up((double)lane + 0.5) * 2.0);
+}
+'''
+  code = runtime.compile_source(src, 'probe.hip')
+  plan = runtime.Plan()
+  plan.abi_version = runtime.ABI_VERSION
+  plan.dim = 1
+  plan.num_inputs = plan.num_outputs = 1
+  plan.elem_size[0] = plan.elem_size[1] = 4
+  plan.num_kernels = 1
+  plan.kernels[0].name = b'probe'
+  plan.kernels[0].block[0] = 64
+  plan.kernels[0].block[1] = plan.kernels[0].block[2] = 1
+  plan.kernels[0].tile[0] = 256
+  plan.num_passes = 1
+  plan.passes[0].fused_iters = 1
+  plan.passes[0].num_kernels = 1
+  lib = runtime.library()
+  handle = ctypes.c_void_p()
+  runtime.check(lib.soda_hip_program_create(code, len(code), ctypes.byref(plan),
+                                            0, ctypes.byref(handle)), 'create')
+  a = np.zeros(256, np.int32)
+  out = np.full(256, -1, np.int32)
+  ext = (ctypes.c_int32 * 1)(256)
+  strd = (ctypes.c_int32 * 1)(1)
+  tin = (runtime.HostTensor * 1)(runtime.HostTensor(a.ctypes.data, ext, strd,
+                                                    None))
+  tout = (runtime.HostTensor * 1)(runtime.HostTensor(out.ctypes.data, ext,
+                                                     strd, None))
+  runtime.check(lib.soda_hip_run_host(handle, tin, tout, 1), 'run')
+  lib.soda_hip_program_destroy(handle)
+  lane = np.arange(64)
+  assert (out[:64] == np.where(lane > 0, lane + 99, 0)).all()
+  assert (out[64:128] == np.where(lane < 63, lane + 101, 0)).all()
+  assert (out[128:192] == np.where(lane > 0, lane + 6, 0)).all()
+  assert (out[192:] == np.where(lane < 63, 2 * lane + 3, 0)).all()
+
+
+CORPUS_2D = ['jacobi2d.soda', 'blur.soda', 'seidel2d.soda', 'sobel2d.soda',
+             'denoise2d.soda', 'skew2d.soda', 'erosion.soda', 'xcorr.soda',
+             'contrast.soda']
+
+
+@pytest.mark.parametrize('name', CORPUS_2D)
+@pytest.mark.parametrize('strategy', ['direct', 'auto'])
+def test_corpus_2d(built, name, strategy):
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name))
+  # ragged on purpose: not a multiple of the strip width or the chunk height
+  extent = (600, 150)
+  _check(stencil, extent, lower.LowerOptions(strategy=strategy, fuse=(2,)))
+
+
+@pytest.mark.parametrize('name', ['heat3d.soda', 'jacobi3d.soda',
+                                  'denoise3d.soda'])
+def test_corpus_3d(built, name):
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name))
+  _check(stencil, (40, 36, 28), lower.LowerOptions())
+
+
+@pytest.mark.parametrize('iterate,fuse', [(1, (4,)), (3, (4,)), (4, (4,)),
+                                          (7, (4, 2)), (9, (8,)), (13, (3,))])
+def test_jacobi2d_temporal_blocking(built, iterate, fuse):
+  """Fused passes + remainder passes give the oracle's result."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=iterate)
+  _check(stencil, (1000, 300), lower.LowerOptions(fuse=fuse), oracle='c')
+
+
+@pytest.mark.parametrize('vec_extent', [(1000, 64), (1002, 64), (1001, 64)])
+def test_row_length_picks_vector_width(built, vec_extent):
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=3)
+  _check(stencil, vec_extent, lower.LowerOptions(fuse=(2,)))
+
+
+def test_blur_reference_init_closed_form(built):
+  """blur on the reference harness's p+q input is p+q+2 (SURVEY 8c KAT)."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('blur.soda'))
+  extent = (2000, 1024)   # BASELINE config 1's grid
+  inputs = _inputs(stencil, extent, kind='ramp')
+  with runtime.Program(stencil, lower.LowerOptions(), extent=extent) as prog:
+    got = prog.run(inputs)['blur_y']
+  q, p = np.indices(extent[::-1])
+  assert (got[:1022, :1998] == (p + q + 2)[:1022, :1998]).all()
+
+
+def test_heat3d_ramp_is_fixed_point(built):
+  """heat3d leaves p+q+r unchanged, bit for bit, for any iterate."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('heat3d.soda'), iterate=5)
+  extent = (48, 40, 32)
+  inputs = _inputs(stencil, extent, kind='ramp')
+  with runtime.Program(stencil, lower.LowerOptions(), extent=extent) as prog:
+    got = prog.run(inputs)['out']
+  lo, hi = stencil.valid_box(extent)
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  assert (got[idx] == inputs['in'][idx]).all()
+
+
+def test_strided_host_arrays(built):
+  """(ptr, extent, stride, min) tensors with non-dense strides."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import numpy_oracle
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=2)
+  extent = (256, 96)
+  big = np.random.default_rng(3).random((96, 300), dtype=np.float32)
+  a = big[:, 20:276]           # row pitch 300, not 256
+  out_big = np.zeros((96, 280), np.float32)
+  out = out_big[:, 8:264]
+  with runtime.Program(stencil, lower.LowerOptions(fuse=(2,)),
+                       extent=extent) as prog:
+    prog.run({'t1': a}, outputs={'t0': out})
+  want = numpy_oracle.run(stencil, {'t1': np.ascontiguousarray(a)})['t0']
+  assert np.array_equal(out, want)
+  assert not out_big[:, :8].any() and not out_big[:, 264:].any()
+
+
+def test_device_entry_and_errors(built):
+  from soda_amd import core, runtime, util
+  from soda_amd.codegen.hip import lower
+  import torch
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=5)
+  extent = (512, 128)
+  a = torch.rand(extent[::-1], device='cuda', dtype=torch.float32)
+  b = torch.empty_like(a)
+  keep = a.clone()
+  with runtime.Program(stencil, lower.LowerOptions(fuse=(4,)),
+                       extent=extent) as prog:
+    stream = torch.cuda.current_stream().cuda_stream
+    prog.run_device([b.data_ptr()], [a.data_ptr()], extent, stream=stream)
+    torch.cuda.synchronize()
+    assert prog.last_launches() == (2, 1)   # one T=4 pass + one T=1 pass
+    assert torch.equal(a, keep), 'inputs must never be written'
+    host = prog.run({'t1': a.cpu().numpy()})['t0']
+    lo, hi = stencil.valid_box(extent)
+    assert np.array_equal(b.cpu().numpy()[lo[1]:hi[1], lo[0]:hi[0]],
+                          host[lo[1]:hi[1], lo[0]:hi[0]])
+    with pytest.raises(util.BackendError):
+      prog.run_device([b.data_ptr()], [a.data_ptr()], extent, iterate=0)
+    with pytest.raises(util.BackendError):
+      prog.run_device([b.data_ptr()], [0], extent)
+
+
+@pytest.mark.parametrize('name,extent,iterate,fuse', [
+    ('jacobi2d.soda', (8192, 8192), 12, (4,)),
+    ('blur.soda', (16384, 16384), 1, ()),
+])
+def test_full_size_properties(built, name, extent, iterate, fuse):
+  """BASELINE-sized grids: compare against the multi-threaded C oracle on the
+  whole valid box (it finishes in seconds), plus size-independent properties:
+  fused and unfused schedules agree bit for bit; a constant field is a fixed
+  point of jacobi2d."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  inputs = _inputs(stencil, extent, seed=11)
+  with runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
+                       extent=extent) as prog:
+    got = prog.run(inputs)
+  want = c_oracle.COracle(stencil).run(inputs)
+  for o in stencil.output_names:
+    lo, hi = stencil.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(got[o][idx], want[o][idx])
+  if fuse:
+    with runtime.Program(stencil, lower.LowerOptions(fuse=()),
+                         extent=extent) as prog:
+      unfused = prog.run(inputs)
+    for o in stencil.output_names:
+      assert np.array_equal(got[o], unfused[o])
