@@ -39,14 +39,16 @@ def parse_args():
       ROOT, 'tests', 'golden', 'soda', 'jacobi2d.soda'))
   ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])
   ap.add_argument('--iterate', type=int, default=100)
-  ap.add_argument('--fuse', type=int, default=4,
-                  help='iterations fused per launch (temporal blocking)')
+  ap.add_argument('--fuse', type=int, nargs='+', default=[12, 4],
+                  help='iterations fused per launch (temporal blocking); the '
+                  'first value is the dominant pass, the others serve the '
+                  'remainder of iterate')
   ap.add_argument('--chunk-rows', type=int, default=64)
   ap.add_argument('--prefetch', type=int, default=2)
   ap.add_argument('--waves-x', type=int, default=1)
-  ap.add_argument('--waves-y', type=int, default=4)
+  ap.add_argument('--waves-y', type=int, default=1)
   ap.add_argument('--strategy', default='auto')
-  ap.add_argument('--exchange-every', type=int, default=20,
+  ap.add_argument('--exchange-every', type=int, default=24,
                   help='iterations between halo exchanges (N > 1)')
   ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -83,7 +85,7 @@ def cpu_baseline(stencil, extent, target_seconds):
   t0 = time.time()
   orc.run(a, iterate=2)
   probe = (time.time() - t0) / 2
-  iters = int(max(2, min(40, target_seconds / max(probe, 1e-6))))
+  iters = int(max(2, min(2000, target_seconds / max(probe, 1e-6))))
   t0 = time.time()
   orc.run(a, iterate=iters)
   dt = time.time() - t0
@@ -122,20 +124,22 @@ def main():
   extent = list(args.extent)
   if args.scaling == 'weak' and world > 1:
     extent[-1] *= world
+  fuses = sorted({f for f in args.fuse if f >= 1}, reverse=True)
+  fuse = fuses[0]
   ex = args.exchange_every
-  if args.fuse > 1:
-    ex = max(args.fuse, ex // args.fuse * args.fuse)
+  if fuse > 1:
+    ex = max(fuse, ex // fuse * fuse)
   slab = sdist.Slab(stencil, extent, world, rank, ex)
   local_extent = slab.local_extent
 
-  def options(fuse):
+  def options(fuse_list):
     return lower.LowerOptions(strategy=args.strategy,
-                              fuse=(fuse,) if fuse > 1 else (),
+                              fuse=tuple(f for f in fuse_list if f > 1),
                               chunk_rows=args.chunk_rows,
                               prefetch=args.prefetch, waves_x=args.waves_x,
                               waves_y=args.waves_y)
 
-  prog = runtime.Program(stencil, options(args.fuse), device=local_rank,
+  prog = runtime.Program(stencil, options(fuses), device=local_rank,
                          extent=local_extent)
   stream = torch.cuda.current_stream().cuda_stream
 
@@ -171,8 +175,19 @@ def main():
     if world > 1:
       tdist.barrier()
 
+  launches_per_step = 0
   for _ in range(args.warmup):
     one_step()
+  torch.cuda.synchronize()
+  # launches of one step: count them once, outside the timed region
+  _orig_step = step_fn
+
+  def counting_step(dst, src, lext, iters):
+    nonlocal launches_per_step
+    _orig_step(dst, src, lext, iters)
+    launches_per_step += prog.last_launches()[0]
+
+  sdist.run(slab, a_bufs, b_bufs, counting_step, args.iterate, tdist)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
@@ -200,7 +215,6 @@ def main():
   local_cells = 1
   for e in local_extent:
     local_cells *= e
-  fuse = max(1, args.fuse)
 
   def dominant():
     step_fn(b_bufs, a_bufs, local_extent, fuse)
@@ -251,14 +265,15 @@ def main():
           'fused_iterations_per_launch': fuse,
           'decomposition': 'slabs along dim %d, halo exchange every %d iters'
                            % (stencil.dim - 1, ex) if world > 1 else 'none',
-          'launches_per_step': prog.last_launches()[0],
+          'launches_per_step': launches_per_step,
+          'passes': [p.fused_iters for p in prog.module.sorted_passes()],
       },
       'roofline': roofline,
   }
 
   if world == 1 and rank == 0:
     if not args.no_single_iter and fuse > 1:
-      prog1 = runtime.Program(stencil, options(1), device=local_rank,
+      prog1 = runtime.Program(stencil, options([1]), device=local_rank,
                               extent=local_extent)
 
       def single():

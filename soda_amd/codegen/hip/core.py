@@ -43,15 +43,27 @@ def add_arguments(parser) -> None:
                       default=2, help='input rows loaded ahead of use')
   parser.add_argument('--hip-extent', type=int, nargs='+', dest='hip_extent',
                       metavar='N', help='grid size for --hip-backend')
+  parser.add_argument('--hip-waves', type=str, dest='hip_waves', default='1x1',
+                      metavar='XxY', help='wavefronts per block along '
+                      'dimension 0 and 1')
+  parser.add_argument('--hip-no-nt-store', action='store_true',
+                      dest='hip_no_nt_store',
+                      help='plain instead of non-temporal output stores')
+  parser.add_argument('--hip-no-xcd-swizzle', action='store_true',
+                      dest='hip_no_xcd_swizzle',
+                      help='do not remap blocks so neighbours share an XCD')
   parser.add_argument('--hip-device', type=int, dest='hip_device', default=0)
 
 
 def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
+  wx, wy = (int(v) for v in args.hip_waves.lower().split('x'))
   return lower.LowerOptions(strategy=args.hip_strategy,
                             fuse=tuple(args.hip_fuse or ()),
                             vec=args.hip_vec,
                             chunk_rows=args.hip_chunk_rows,
-                            prefetch=args.hip_prefetch)
+                            prefetch=args.hip_prefetch, waves_x=wx, waves_y=wy,
+                            nt_store=not args.hip_no_nt_store,
+                            xcd_swizzle=not args.hip_no_xcd_swizzle)
 
 
 def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:

@@ -12,6 +12,8 @@
 //
 // gfx950 only: wave64, DPP wave_shr/wave_shl (GFX9 encodings).
 
+// hiprtc (the JIT path) has no <stdint.h>; offline hipcc builds of this text do
+#ifdef __HIPCC_RTC__
 typedef __INT8_TYPE__ int8_t;
 typedef __UINT8_TYPE__ uint8_t;
 typedef __INT16_TYPE__ int16_t;
@@ -20,6 +22,10 @@ typedef __INT32_TYPE__ int32_t;
 typedef __UINT32_TYPE__ uint32_t;
 typedef __INT64_TYPE__ int64_t;
 typedef __UINT64_TYPE__ uint64_t;
+#else
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#endif
 
 // must match soda_hip_kargs_t in include/soda_hip.h
 struct soda_hip_kargs_t {
@@ -29,7 +35,7 @@ struct soda_hip_kargs_t {
   int32_t ntile[4];
 };
 
-#define SODA_DEV static __device__ __forceinline__
+#define SODA_DEV static __device__ inline __attribute__((always_inline))
 
 // min/max/abs of the DSL: arguments evaluated once, result type given by the
 // usual arithmetic conversions (same as the CPU oracle's macros in ir.py)
@@ -115,13 +121,14 @@ struct soda_vec {
   typedef T type __attribute__((ext_vector_type(V)));
 };
 
-template <class T, int V>
+template <class T, int V, bool kNonTemporal = false>
 SODA_DEV void soda_load_frag(T (&dst)[V], const T* __restrict__ p) {
   if constexpr (V == 1) {
-    dst[0] = *p;
+    dst[0] = kNonTemporal ? __builtin_nontemporal_load(p) : *p;
   } else {
     typedef typename soda_vec<T, V>::type vec_t;
-    const vec_t t = *reinterpret_cast<const vec_t*>(p);
+    const vec_t* vp = reinterpret_cast<const vec_t*>(p);
+    const vec_t t = kNonTemporal ? __builtin_nontemporal_load(vp) : *vp;
 #pragma unroll
     for (int e = 0; e < V; ++e) dst[e] = t[e];
   }
@@ -133,15 +140,19 @@ SODA_DEV void soda_zero_frag(T (&dst)[V]) {
   for (int e = 0; e < V; ++e) dst[e] = (T)0;
 }
 
-template <class T, int V>
+template <class T, int V, bool kNonTemporal = false>
 SODA_DEV void soda_store_frag(T* __restrict__ p, const T (&src)[V]) {
   if constexpr (V == 1) {
-    *p = src[0];
+    if constexpr (kNonTemporal) __builtin_nontemporal_store(src[0], p);
+    else *p = src[0];
   } else {
     typedef typename soda_vec<T, V>::type vec_t;
     vec_t t;
 #pragma unroll
     for (int e = 0; e < V; ++e) t[e] = src[e];
-    *reinterpret_cast<vec_t*>(p) = t;
+    if constexpr (kNonTemporal)
+      __builtin_nontemporal_store(t, reinterpret_cast<vec_t*>(p));
+    else
+      *reinterpret_cast<vec_t*>(p) = t;
   }
 }

@@ -23,8 +23,14 @@ LIB_PATH = os.path.join(_HERE, 'libsoda_hip.so')
 CACHE_DIR = os.environ.get('SODA_HIP_CACHE',
                            os.path.join(_HERE, '_jit_cache'))
 ARCH = 'gfx950'
+# -ffp-contract=off: bit-identical fp32 results to the CPU oracle (no FMA).
+# -fno-slp-vectorize: hipcc would otherwise pair neighbouring cells into
+#   v_pk_add_f32/v_pk_mul_f32; on gfx950 those issue at half the rate of the
+#   scalar forms and need v_mov shuffles to line registers up (measured: same
+#   instruction count, ~25 % more cycles, 19 more VGPRs on jacobi2d T=8).
 COMPILE_OPTIONS = ('--offload-arch=%s' % ARCH, '-O3', '-ffp-contract=off',
-                   '-std=c++17')
+                   '-fno-slp-vectorize', '-std=c++17') + tuple(
+                       os.environ.get('SODA_HIP_EXTRA_FLAGS', '').split())
 
 MAX_DIM = 4
 MAX_TENSORS = 16

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Kernel-parameter sweep on one GPU: times the dominant pass of a program for
+every combination of knobs, interleaved over rounds in ONE process (so numbers
+are comparable), HIP events on the launch stream.  Prints one line per config,
+sorted by time.  Usage: python tools/sweep.py --fuse 1 4 --chunk 32 64 ..."""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--soda', default=os.path.join(ROOT, 'tests/golden/soda/jacobi2d.soda'))
+  ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])
+  ap.add_argument('--fuse', type=int, nargs='+', default=[1])
+  ap.add_argument('--chunk', type=int, nargs='+', default=[64])
+  ap.add_argument('--prefetch', type=int, nargs='+', default=[2])
+  ap.add_argument('--waves', nargs='+', default=['1x4'])
+  ap.add_argument('--nt-store', type=int, nargs='+', default=[0])
+  ap.add_argument('--nt-load', type=int, nargs='+', default=[0])
+  ap.add_argument('--xcd', type=int, nargs='+', default=[0])
+  ap.add_argument('--rounds', type=int, default=3)
+  ap.add_argument('--reps', type=int, default=20)
+  ap.add_argument('--out', default=None)
+  args = ap.parse_args()
+  import torch
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  dev = torch.device('cuda', 0)
+  shape = tuple(args.extent[::-1])
+  configs = list(itertools.product(args.fuse, args.chunk, args.prefetch,
+                                   args.waves, args.nt_store, args.nt_load,
+                                   args.xcd))
+  progs = []
+  stream = torch.cuda.current_stream().cuda_stream
+  for fuse, chunk, pf, waves, nts, ntl, xcd in configs:
+    st = core.from_file(args.soda, iterate=fuse)
+    wx, wy = map(int, waves.split('x'))
+    opts = lower.LowerOptions(fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk,
+                              prefetch=pf, waves_x=wx, waves_y=wy,
+                              nt_store=bool(nts), nt_load=bool(ntl),
+                              xcd_swizzle=bool(xcd))
+    try:
+      progs.append((runtime.Program(st, opts, extent=args.extent), st, fuse))
+    except Exception as e:  # noqa
+      print('skip', fuse, chunk, pf, waves, str(e)[:200])
+      progs.append(None)
+  st0 = core.from_file(args.soda)
+  ins = [torch.rand(shape, device=dev, dtype=torch.float32) for _ in st0.input_names]
+  outs = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in st0.output_names]
+  times = {i: [] for i in range(len(configs))}
+  for r in range(args.rounds):
+    for i, item in enumerate(progs):
+      if item is None:
+        continue
+      prog, st, fuse = item
+      def go():
+        prog.run_device([t.data_ptr() for t in outs], [t.data_ptr() for t in ins],
+                        args.extent, iterate=fuse, stream=stream)
+      go()
+      a, b = runtime.Event(), runtime.Event()
+      a.record(stream)
+      for _ in range(args.reps):
+        go()
+      b.record(stream)
+      times[i].append(a.elapsed_ms(b) / args.reps)
+  cells = 1
+  for e in args.extent:
+    cells *= e
+  rows = []
+  for i, cfg in enumerate(configs):
+    if not times[i]:
+      continue
+    best = min(times[i]); med = sorted(times[i])[len(times[i]) // 2]
+    fuse = cfg[0]
+    rows.append(dict(fuse=fuse, chunk=cfg[1], prefetch=cfg[2], waves=cfg[3],
+                     nt_store=cfg[4], nt_load=cfg[5], xcd=cfg[6], ms_min=best,
+                     ms_med=med, GBs=cells * 8 / best / 1e6,
+                     Gcell_iters=cells * fuse / best / 1e6))
+  rows.sort(key=lambda r: (r['fuse'], r['ms_min']))
+  for r in rows:
+    print(json.dumps(r))
+  if args.out:
+    with open(args.out, 'w') as f:
+      json.dump(rows, f, indent=1)
+
+
+if __name__ == '__main__':
+  main()
