@@ -46,9 +46,12 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-waves', type=str, dest='hip_waves', default='1x1',
                       metavar='XxY', help='wavefronts per block along '
                       'dimension 0 and 1')
-  parser.add_argument('--hip-no-nt-store', action='store_true',
-                      dest='hip_no_nt_store',
-                      help='plain instead of non-temporal output stores')
+  parser.add_argument('--hip-nt-store', action='store_true',
+                      dest='hip_nt_store',
+                      help='non-temporal instead of plain output stores')
+  parser.add_argument('--hip-no-nt-load', action='store_true',
+                      dest='hip_no_nt_load',
+                      help='plain instead of non-temporal input loads')
   parser.add_argument('--hip-no-xcd-swizzle', action='store_true',
                       dest='hip_no_xcd_swizzle',
                       help='do not remap blocks so neighbours share an XCD')
@@ -62,7 +65,8 @@ def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
                             vec=args.hip_vec,
                             chunk_rows=args.hip_chunk_rows,
                             prefetch=args.hip_prefetch, waves_x=wx, waves_y=wy,
-                            nt_store=not args.hip_no_nt_store,
+                            nt_store=args.hip_nt_store,
+                            nt_load=not args.hip_no_nt_load,
                             xcd_swizzle=not args.hip_no_xcd_swizzle)
 
 

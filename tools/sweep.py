@@ -26,6 +26,7 @@ def main():
   ap.add_argument('--xcd', type=int, nargs='+', default=[0])
   ap.add_argument('--rounds', type=int, default=3)
   ap.add_argument('--reps', type=int, default=20)
+  ap.add_argument('--launches', type=int, default=1, help='launches per call (ping-pong through the program temporaries, as in a real run)')
   ap.add_argument('--out', default=None)
   args = ap.parse_args()
   import torch
@@ -39,7 +40,7 @@ def main():
   progs = []
   stream = torch.cuda.current_stream().cuda_stream
   for fuse, chunk, pf, waves, nts, ntl, xcd in configs:
-    st = core.from_file(args.soda, iterate=fuse)
+    st = core.from_file(args.soda, iterate=fuse * args.launches)
     wx, wy = map(int, waves.split('x'))
     opts = lower.LowerOptions(fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk,
                               prefetch=pf, waves_x=wx, waves_y=wy,
@@ -61,14 +62,14 @@ def main():
       prog, st, fuse = item
       def go():
         prog.run_device([t.data_ptr() for t in outs], [t.data_ptr() for t in ins],
-                        args.extent, iterate=fuse, stream=stream)
+                        args.extent, iterate=fuse * args.launches, stream=stream)
       go()
       a, b = runtime.Event(), runtime.Event()
       a.record(stream)
       for _ in range(args.reps):
         go()
       b.record(stream)
-      times[i].append(a.elapsed_ms(b) / args.reps)
+      times[i].append(a.elapsed_ms(b) / args.reps / args.launches)
   cells = 1
   for e in args.extent:
     cells *= e
