@@ -121,6 +121,17 @@ int soda_hip_device_count(int* count) {
   return SODA_HIP_OK;
 }
 
+size_t soda_hip_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(soda_hip_kargs_t);
+    case 1: return sizeof(soda_hip_kernel_desc_t);
+    case 2: return sizeof(soda_hip_pass_desc_t);
+    case 3: return sizeof(soda_hip_plan_t);
+    case 4: return sizeof(soda_hip_host_tensor_t);
+    default: return 0;
+  }
+}
+
 int soda_hip_compile(const char* source, const char* name,
                      const char* const* options, int32_t num_options,
                      void** code, size_t* code_size) {

@@ -21,7 +21,7 @@ _TOKEN_RE = re.compile(
     r'''
     (?P<ws>[ \t\r\n]+)
   | (?P<comment>\#[^\n]*)
-  | (?P<float>(?:(?:\d*\.\d+|\d+\.)(?:[+-]?[Ee]\d+)?|\d+[+-]?[Ee]\d+)[FfLl]?|\d+[Ff])
+  | (?P<float>(?:(?:\d*\.\d+|\d+\.)(?:[Ee][+-]?\d+)?|\d+[Ee][+-]?\d+)[FfLl]?|\d+[Ff])
   | (?P<int>0[Xx][0-9a-fA-F]+[UuLl]*|0[Bb][01]+[UuLl]*|\d+[UuLl]*)
   | (?P<id>[A-Za-z_][A-Za-z0-9_]*)
   | (?P<op>\|\||&&|==|!=|<=|>=|[-+*/%~!|^&<>()\[\],:.=])

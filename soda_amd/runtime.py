@@ -83,6 +83,7 @@ API = {
     'soda_hip_status_string': (ctypes.c_char_p, [ctypes.c_int]),
     'soda_hip_last_error': (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
     'soda_hip_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'soda_hip_sizeof': (ctypes.c_size_t, [ctypes.c_int]),
     'soda_hip_compile': (ctypes.c_int, [
         ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), _i32,
         _pvp, ctypes.POINTER(ctypes.c_size_t)
@@ -143,6 +144,14 @@ def library() -> ctypes.CDLL:
     if lib.soda_hip_abi_version() != ABI_VERSION:
       raise util.BackendError('libsoda_hip.so has ABI version %d, expected %d' %
                               (lib.soda_hip_abi_version(), ABI_VERSION))
+    for which, mirror in ((1, KernelDesc), (2, PassDesc), (3, Plan),
+                          (4, HostTensor)):
+      if lib.soda_hip_sizeof(which) != ctypes.sizeof(mirror):
+        raise util.BackendError(
+            'struct layout mismatch between libsoda_hip.so and runtime.py '
+            '(%s: %d vs %d bytes); rebuild the library' %
+            (mirror.__name__, lib.soda_hip_sizeof(which),
+             ctypes.sizeof(mirror)))
     _lib = lib
   return _lib
 

@@ -1,0 +1,186 @@
+"""CPU-side checks of the HIP backend: the C-ABI library loads and exports
+every symbol include/soda_hip.h declares, struct mirrors match, every corpus
+program lowers and JIT-compiles for gfx950 (hiprtc needs no GPU), the CLI
+behaves like the reference driver, and the product path fails loudly -- never
+falls back -- when it cannot run on a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, SODA_DIR, soda_path
+from soda_amd import core, util
+
+
+def _declared_symbols():
+  text = open(os.path.join(ROOT, 'include', 'soda_hip.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(soda_hip_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+  from soda_amd import runtime
+  lib = ctypes.CDLL(runtime.LIB_PATH)
+  declared = _declared_symbols()
+  assert len(declared) >= 20
+  for name in declared:
+    assert hasattr(lib, name), 'libsoda_hip.so lacks %s' % name
+  assert sorted(runtime.API) == declared, 'runtime.API and the header differ'
+
+
+def test_struct_mirrors_match(built):
+  from soda_amd import runtime
+  lib = runtime.library()   # also runs the built-in layout check
+  assert lib.soda_hip_abi_version() == runtime.ABI_VERSION
+  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 4 * 4 + 4 * 4
+  assert lib.soda_hip_sizeof(3) == ctypes.sizeof(runtime.Plan)
+  assert lib.soda_hip_sizeof(99) == 0
+  assert lib.soda_hip_status_string(5) == b'no usable GPU'
+
+
+def test_kargs_struct_in_device_runtime_matches_header():
+  from soda_amd.codegen.hip import lower
+  rt = lower.runtime_text()
+  assert 'void* buf[16];' in rt and 'int64_t stride[4];' in rt
+  assert 'int32_t extent[4];' in rt and 'int32_t ntile[4];' in rt
+
+
+ALL = sorted(f for f in os.listdir(SODA_DIR) if f.endswith('.soda')) + [
+    'skew2d.soda']
+
+
+@pytest.mark.parametrize('name', ALL)
+def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name))
+  fuse = (3,) if len(stencil.input_names) == len(stencil.output_names) else ()
+  opts = lower.LowerOptions(fuse=fuse)
+  opts.vec = runtime.pick_vec(stencil, None)
+  mod = lower.lower(stencil, opts)
+  plan = runtime.make_plan(mod)
+  assert plan.passes[plan.num_passes - 1].fused_iters == 1
+  code = runtime.compile_source(mod.source, name, cache_dir=str(tmp_path))
+  assert code[:4] == b'\x7fELF'
+  for k in mod.kernels:
+    assert k.name.encode() in code
+  if stencil.dim == 2 and name not in ('erosion.soda', 'xcorr.soda',
+                                       'contrast.soda'):
+    assert all(p.kind == 'march2d' for p in mod.passes)
+    assert sorted(p.fused_iters for p in mod.passes) == sorted({1} | set(fuse))
+  else:
+    assert all(p.kind == 'direct' for p in mod.passes)
+
+
+def test_march2d_geometry_for_jacobi2d():
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  opts = lower.LowerOptions(fuse=(4,), vec=4, chunk_rows=64)
+  mod = lower.lower(stencil, opts)
+  by_t = {p.fused_iters: p for p in mod.passes}
+  k4 = mod.kernels[by_t[4].kernels[0]]
+  k1 = mod.kernels[by_t[1].kernels[0]]
+  # 4 fused iterations: 4 halo cells per side = 1 lane -> 62 lanes x 4 cells
+  assert k4.tile[:2] == (248, 64) and k4.block == (64, 1, 1)
+  assert k1.tile[:2] == (248, 64)
+  assert by_t[4].traffic_model['warm_rows'] == 2 + 4 + 4
+  assert by_t[4].traffic_model['bytes_per_cell_min'] == 8
+  src = mod.source
+  assert 'soda_lane_dn' in src and 'soda_lane_up' in src
+  assert '__shared__' not in src            # registers + DPP only
+
+
+def test_vector_width_follows_row_length():
+  from soda_amd import runtime
+  j = core.from_file(soda_path('jacobi2d.soda'))
+  b = core.from_file(soda_path('blur.soda'))
+  assert runtime.pick_vec(j, (8192, 8192)) == 4
+  assert runtime.pick_vec(j, (1002, 64)) == 2
+  assert runtime.pick_vec(j, (1001, 64)) == 1
+  assert runtime.pick_vec(b, (16384, 16384)) == 8
+  assert runtime.pick_vec(b, (2000, 1024)) == 8
+  assert runtime.pick_vec(b, (2004, 10)) == 4
+
+
+def test_unsupported_programs_are_rejected():
+  from soda_amd.codegen.hip import lower
+  with pytest.raises(util.SemanticError, match='8/16/32/64-bit'):
+    lower.lower(core.from_text(
+        'kernel: k\nburst width: 64\nunroll factor: 1\niterate: 1\n'
+        'input uint6: a(8, *)\noutput uint6: o(0, 0) = a(0, 0)'))
+  with pytest.raises(util.SemanticError, match='param'):
+    lower.lower(core.from_text(
+        'kernel: k\nburst width: 64\nunroll factor: 1\niterate: 1\n'
+        'input float: a(8, *)\nparam float: p[4]\n'
+        'output float: o(0, 0) = a(0, 0) * p[1]'))
+  with pytest.raises(util.SemanticError, match='march2d'):
+    lower.lower(core.from_file(soda_path('heat3d.soda')),
+                lower.LowerOptions(strategy='march'))
+
+
+def test_no_cpu_fallback_without_gpu(built):
+  """On a box without a GPU the product path must raise, not compute."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  if runtime.device_count() > 0:
+    pytest.skip('a GPU is present')
+  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  with pytest.raises(util.BackendError, match='GPU|device'):
+    runtime.Program(stencil, lower.LowerOptions(), extent=(64, 64))
+
+
+def test_product_code_never_imports_the_oracle():
+  for dirpath, _, files in os.walk(os.path.join(ROOT, 'soda_amd')):
+    for f in files:
+      if f.endswith(('.py', '.cpp', '.h')):
+        text = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+        assert 'oracle/' not in text.replace('CPU oracle', ''), f
+
+
+def _sodac(*argv):
+  return subprocess.run([sys.executable, '-m', 'soda_amd.sodac'] + list(argv),
+                        cwd=ROOT, capture_output=True, text=True)
+
+
+def test_sodac_prints_hip_kernel(built, tmp_path):
+  out = tmp_path / 'k.hip'
+  r = _sodac(soda_path('blur.soda'), '--hip-kernel', str(out))
+  assert r.returncode == 0, r.stderr
+  text = out.read_text()
+  assert 'extern "C" __global__' in text and 'blur_march2d' in text
+  r = _sodac(soda_path('jacobi2d.soda'), '--hip-kernel', '-', '--iterate', '8',
+             '--hip-fuse', '8')
+  assert r.returncode == 0 and 'jacobi2d_march2d_T8' in r.stdout
+  r = _sodac('-', '--hip-kernel', '-')
+  assert r.returncode != 0   # empty stdin is a syntax error -> exit 1
+
+
+def test_sodac_error_exit_codes(tmp_path):
+  bad = tmp_path / 'bad.soda'
+  bad.write_text('kernel: k\nburst width: 64\n')
+  r = _sodac(str(bad), '--hip-kernel', '-')
+  assert r.returncode == 1 and 'expected' in r.stderr
+  r = _sodac(soda_path('blur.soda'), '--iterate', '0', '--hip-kernel', '-')
+  assert r.returncode == 1 and 'cannot iterate 0 times' in r.stderr
+  r = _sodac(soda_path('blur.soda'), '--iterate', '2', '--hip-kernel', '-')
+  assert r.returncode == 0   # blur: 1 input, 1 output, same type -> iterable
+
+
+def test_backend_plugin_surface():
+  """add_arguments / print_code, the reference's backend API
+  (sodac.py:99-102,198-200)."""
+  import argparse
+  from soda_amd.codegen.hip import core as hip
+  parser = argparse.ArgumentParser()
+  hip.add_arguments(parser)
+  args = parser.parse_args(['--hip-kernel', '-', '--hip-fuse', '2', '6'])
+  assert args.hip_kernel == '-' and args.hip_fuse == [2, 6]
+  assert not args.hip_backend
+  opts = hip.options_from_args(args)
+  assert opts.fuse == (2, 6) and opts.nt_load and not opts.nt_store
+  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  assert hip.default_extent(stencil) == [32, 6]   # frt/host.py:454-461

@@ -1,0 +1,201 @@
+"""Pins the CPU oracle (test infrastructure under oracle/).
+
+The reference holds no numeric vectors for this path, so the
+oracle is pinned by: closed-form known answers derived from the reference
+semantics (frt/host.py:558-624), three restatements that must agree bit for
+bit (numpy, generated C, hand-written C that never touches this repo's
+parser), the reference harness's input recipe, and committed golden outputs.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT, soda_path
+from soda_amd import core
+
+
+@pytest.fixture(scope='module')
+def kat(built):
+  lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_build', 'libkat_kernels.so'))
+  return lib
+
+
+@pytest.fixture(scope='module')
+def ref_init(built):
+  return ctypes.CDLL(os.path.join(ROOT, 'oracle', '_build', 'libref_init.so'))
+
+
+def _ptr(a):
+  return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _reference_floats(ref_init, shape):
+  a = np.empty(shape, np.float32)
+  ref_init.ref_init_float(_ptr(a), ctypes.c_int64(a.size))
+  return a
+
+
+def test_reference_input_recipe(ref_init):
+  """libstdc++ default_random_engine + uniform_real_distribution<double>(0,1),
+  memory order (frt/host.py:503-528): minstd_rand0, two draws per double."""
+  a = _reference_floats(ref_init, (4, 5))
+  x, vals = 1, []
+  for _ in range(4):
+    lo = x = x * 16807 % 2147483647
+    hi = x = x * 16807 % 2147483647
+    vals.append(((lo - 1) + (hi - 1) * 2147483646.0) / 2147483646.0**2)
+  assert np.array_equal(a.ravel()[:4], np.array(vals).astype(np.float32))
+  assert a.min() >= 0.0 and a.max() < 1.0
+
+
+@pytest.mark.parametrize('iterate', [1, 2, 5])
+def test_jacobi2d_three_restatements_agree(kat, ref_init, iterate):
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path('jacobi2d.soda'))
+  a = _reference_floats(ref_init, (40, 48))
+  want = np.empty_like(a)
+  assert kat.kat_jacobi2d(_ptr(a), _ptr(want), 48, 40, iterate) == 0
+  assert np.array_equal(numpy_oracle.run(st, {'t1': a}, iterate)['t0'], want)
+  assert np.array_equal(c_oracle.COracle(st).run({'t1': a}, iterate)['t0'], want)
+  lo, hi = st.valid_box((48, 40), iterate=iterate)
+  assert lo == (iterate, iterate) and hi == (48 - iterate, 40 - iterate)
+  assert not want[:iterate].any() and not want[:, :iterate].any()
+
+
+def test_blur_three_restatements_agree(kat):
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path('blur.soda'))
+  a = np.random.default_rng(0).integers(0, 65536, (30, 50)).astype(np.uint16)
+  want = np.empty_like(a)
+  assert kat.kat_blur(_ptr(a), _ptr(want), 50, 30) == 0
+  assert np.array_equal(numpy_oracle.run(st, {'input': a})['blur_y'], want)
+  assert np.array_equal(c_oracle.COracle(st).run({'input': a})['blur_y'], want)
+
+
+@pytest.mark.parametrize('iterate', [1, 2, 3])
+def test_heat3d_three_restatements_agree(kat, iterate):
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path('heat3d.soda'))
+  a = np.random.default_rng(2).random((12, 14, 16), dtype=np.float32)
+  want = np.empty_like(a)
+  assert kat.kat_heat3d(_ptr(a), _ptr(want), 16, 14, 12, iterate) == 0
+  assert np.array_equal(numpy_oracle.run(st, {'in': a}, iterate)['out'], want)
+  assert np.array_equal(c_oracle.COracle(st).run({'in': a}, iterate)['out'], want)
+
+
+def test_skew2d_store_index_and_asymmetric_taps(kat):
+  """Non-zero store index + asymmetric taps: orientation errors that the
+  symmetric benchmark stencils cannot show."""
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path('skew2d.soda'))
+  a = np.random.default_rng(5).random((20, 24), dtype=np.float32)
+  want = np.empty_like(a)
+  assert kat.kat_skew2d(_ptr(a), _ptr(want), 24, 20) == 0
+  assert np.array_equal(numpy_oracle.run(st, {'a': a})['c'], want)
+  assert np.array_equal(c_oracle.COracle(st).run({'a': a})['c'], want)
+  assert st.valid_box((24, 20)) == ((2, 2), (22, 18))
+
+
+def test_blur_closed_form_on_reference_init():
+  """BASELINE config 1 (tests/src/blur.soda, 2000 x 1024, CPU): the reference
+  harness's integer init p+q gives blur_x = p+q+1 and blur_y = p+q+2 exactly
+  on [0,1998) x [0,1022), zero elsewhere."""
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path('blur.soda'))
+  q, p = np.indices((1024, 2000))
+  a = (p + q).astype(np.uint16)
+  for got in (numpy_oracle.run(st, {'input': a}, keep_locals=True),
+              c_oracle.COracle(st).run({'input': a})):
+    assert np.array_equal(got['blur_y'][:1022, :1998], (p + q + 2)[:1022, :1998])
+    assert not got['blur_y'][1022:].any() and not got['blur_y'][:, 1998:].any()
+    if 'blur_x' in got:
+      assert np.array_equal(got['blur_x'][:1022], (p + q + 1)[:1022])
+
+
+@pytest.mark.parametrize('iterate', [1, 4])
+def test_heat3d_ramp_is_a_fixed_point(iterate):
+  """Coefficients are powers of two summing to 1: p+q+r is reproduced exactly
+  (robust to FMA/association; pins 3-D indexing and the box shrink)."""
+  from oracle import numpy_oracle
+  st = core.from_file(soda_path('heat3d.soda'))
+  a = np.indices((20, 18, 16)).sum(axis=0).astype(np.float32)
+  got = numpy_oracle.run(st, {'in': a}, iterate)['out']
+  n = iterate
+  assert np.array_equal(got[n:-n, n:-n, n:-n], a[n:-n, n:-n, n:-n])
+  assert not got[:n].any()
+
+
+def test_jacobi2d_linear_field_within_tolerance():
+  from oracle import numpy_oracle
+  st = core.from_file(soda_path('jacobi2d.soda'))
+  q, p = np.indices((40, 50))
+  a = (0.25 * p + 0.5 * q + 1).astype(np.float32)
+  got = numpy_oracle.run(st, {'t1': a}, 6)['t0']
+  lo, hi = st.valid_box((50, 40), iterate=6)
+  assert numpy_oracle.compare(got, a, lo, hi) == 0          # 1e-5 rule
+  assert numpy_oracle.compare(got, a * 1.001, lo, hi) > 0
+
+
+def test_integer_semantics():
+  """C promotion, truncating division, wrap on store (grammar.py:123-136)."""
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_text('kernel: k\nburst width: 64\nunroll factor: 1\n'
+                      'iterate: 1\ninput int16: a(8, *)\n'
+                      'local int16: d(0, 0) = (a(0, 0) - a(1, 0)) / 3\n'
+                      'local uint16: m(0, 0) = a(0, 0) * a(0, 0)\n'
+                      'output int16: o(0, 0) = int32(d(0, 0)) * 257 % 7 + '
+                      'm(0, 0) / 256 - (a(0, 1) > a(0, 0))')
+  a = np.array([[-7, 5, 300, -300, 32767, -32768, 11, 0],
+                [1, 2, 3, 4, 5, 6, 7, 8]], np.int16)
+  got = numpy_oracle.run(st, {'a': a}, keep_locals=True)
+  assert got['d'][0, :3].tolist() == [-4, -98, 200]      # trunc toward zero
+  assert got['m'][0, 2] == np.uint16(300 * 300 % 65536)
+  assert np.array_equal(c_oracle.COracle(st).run({'a': a})['o'], got['o'])
+
+
+def test_min_max_calls_and_sqrt():
+  from oracle import c_oracle, numpy_oracle
+  for name, feed in (('erosion.soda', 'input'), ('denoise2d.soda', None)):
+    st = core.from_file(soda_path(name))
+    rng = np.random.default_rng(9)
+    ins = {}
+    for n, t in zip(st.input_names, st.input_types):
+      if t.is_float:
+        ins[n] = rng.random((40, 48), dtype=np.float32)
+      else:
+        ins[n] = rng.integers(-2000, 2000, (40, 48)).astype(t.np_name)
+    a = numpy_oracle.run(st, ins)
+    b = c_oracle.COracle(st).run(ins)
+    for o in st.output_names:
+      assert np.array_equal(a[o], b[o]), name
+
+
+@pytest.mark.parametrize('name', ['jacobi2d', 'blur', 'heat3d', 'skew2d',
+                                  'sobel2d', 'denoise2d'])
+def test_committed_golden_vectors(name):
+  """tests/golden/*.npz, written by tests/golden/make_golden.py."""
+  from oracle import numpy_oracle
+  path = os.path.join(GOLDEN_DIR, '%s.npz' % name)
+  data = np.load(path)
+  st = core.from_file(soda_path('%s.soda' % name), iterate=int(data['iterate']))
+  ins = {n: data['in_' + n] for n in st.input_names}
+  got = numpy_oracle.run(st, ins)
+  for o in st.output_names:
+    assert np.array_equal(got[o], data['out_' + o])
+
+
+def test_compare_rule():
+  from oracle import numpy_oracle
+  want = np.full((4, 4), 100.0, np.float32)
+  got = want.copy()
+  got[1, 1] += 0.0005       # abs > 1e-5 but rel = 5e-6: passes, as in the ref
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 0
+  got[2, 2] += 0.01
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 1
+  assert numpy_oracle.compare(got, want, (0, 0), (2, 2)) == 0
+  a = np.arange(16, dtype=np.uint16).reshape(4, 4)
+  b = a.copy()
+  b[3, 3] += 1
+  assert numpy_oracle.compare(b, a, (0, 0), (4, 4)) == 1
