@@ -40,7 +40,9 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-chunk-rows', type=int, dest='hip_chunk_rows',
                       default=64, help='rows one wavefront marches over')
   parser.add_argument('--hip-prefetch', type=int, dest='hip_prefetch',
-                      default=2, help='input rows loaded ahead of use')
+                      default=None, help='input rows loaded ahead of use')
+  parser.add_argument('--hip-tile-rows', type=int, dest='hip_tile_rows',
+                      default=None, help='3-D: output rows held per wavefront')
   parser.add_argument('--hip-extent', type=int, nargs='+', dest='hip_extent',
                       metavar='N', help='grid size for --hip-backend')
   parser.add_argument('--hip-waves', type=str, dest='hip_waves', default='1x1',
@@ -66,7 +68,8 @@ def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
                             chunk_rows=args.hip_chunk_rows,
                             prefetch=args.hip_prefetch, waves_x=wx, waves_y=wy,
                             nt_store=args.hip_nt_store,
-                            nt_load=not args.hip_no_nt_load,
+                            nt_load=False if args.hip_no_nt_load else None,
+                            tile_rows=args.hip_tile_rows,
                             xcd_swizzle=not args.hip_no_xcd_swizzle)
 
 

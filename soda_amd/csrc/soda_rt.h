@@ -70,6 +70,15 @@ SODA_DEV int soda_dpp_shl1(int v) {
                                      false);
 }
 
+// same, but the lane with no source (0 resp. 63) receives ITS OWN `edge`
+// value: DPP leaves `old` in lanes whose source lane does not exist
+SODA_DEV int soda_dpp_shr1_or(int v, int edge) {
+  return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false);
+}
+SODA_DEV int soda_dpp_shl1_or(int v, int edge) {
+  return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false);
+}
+
 template <class T, int kSize = sizeof(T)>
 struct soda_lane_shift;
 
@@ -80,6 +89,14 @@ struct soda_lane_shift<T, 4> {
   }
   SODA_DEV T up(T v) {
     return __builtin_bit_cast(T, soda_dpp_shl1(__builtin_bit_cast(int, v)));
+  }
+  SODA_DEV T dn_or(T v, T edge) {
+    return __builtin_bit_cast(T, soda_dpp_shr1_or(__builtin_bit_cast(int, v),
+                                                  __builtin_bit_cast(int, edge)));
+  }
+  SODA_DEV T up_or(T v, T edge) {
+    return __builtin_bit_cast(T, soda_dpp_shl1_or(__builtin_bit_cast(int, v),
+                                                  __builtin_bit_cast(int, edge)));
   }
 };
 
@@ -98,22 +115,40 @@ struct soda_lane_shift<T, 8> {
     p.hi = soda_dpp_shl1(p.hi);
     return __builtin_bit_cast(T, p);
   }
+  SODA_DEV T dn_or(T v, T edge) {
+    pair p = __builtin_bit_cast(pair, v), q = __builtin_bit_cast(pair, edge);
+    p.lo = soda_dpp_shr1_or(p.lo, q.lo);
+    p.hi = soda_dpp_shr1_or(p.hi, q.hi);
+    return __builtin_bit_cast(T, p);
+  }
+  SODA_DEV T up_or(T v, T edge) {
+    pair p = __builtin_bit_cast(pair, v), q = __builtin_bit_cast(pair, edge);
+    p.lo = soda_dpp_shl1_or(p.lo, q.lo);
+    p.hi = soda_dpp_shl1_or(p.hi, q.hi);
+    return __builtin_bit_cast(T, p);
+  }
 };
 
 template <class T>
 struct soda_lane_shift<T, 2> {  // widened: one VGPR per element
   SODA_DEV T dn(T v) { return (T)soda_dpp_shr1((int)v); }
   SODA_DEV T up(T v) { return (T)soda_dpp_shl1((int)v); }
+  SODA_DEV T dn_or(T v, T edge) { return (T)soda_dpp_shr1_or((int)v, (int)edge); }
+  SODA_DEV T up_or(T v, T edge) { return (T)soda_dpp_shl1_or((int)v, (int)edge); }
 };
 
 template <class T>
 struct soda_lane_shift<T, 1> {
   SODA_DEV T dn(T v) { return (T)soda_dpp_shr1((int)v); }
   SODA_DEV T up(T v) { return (T)soda_dpp_shl1((int)v); }
+  SODA_DEV T dn_or(T v, T edge) { return (T)soda_dpp_shr1_or((int)v, (int)edge); }
+  SODA_DEV T up_or(T v, T edge) { return (T)soda_dpp_shl1_or((int)v, (int)edge); }
 };
 
 template <class T> SODA_DEV T soda_lane_dn(T v) { return soda_lane_shift<T>::dn(v); }
 template <class T> SODA_DEV T soda_lane_up(T v) { return soda_lane_shift<T>::up(v); }
+template <class T> SODA_DEV T soda_lane_dn_or(T v, T edge) { return soda_lane_shift<T>::dn_or(v, edge); }
+template <class T> SODA_DEV T soda_lane_up_or(T v, T edge) { return soda_lane_shift<T>::up_or(v, edge); }
 
 // ---- row fragments: V consecutive cells of one row per lane ----------------
 template <class T, int V>

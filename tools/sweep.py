@@ -24,9 +24,13 @@ def main():
   ap.add_argument('--nt-store', type=int, nargs='+', default=[0])
   ap.add_argument('--nt-load', type=int, nargs='+', default=[0])
   ap.add_argument('--xcd', type=int, nargs='+', default=[0])
+  ap.add_argument('--vec', type=int, nargs='+', default=[4])
+  ap.add_argument('--tile-rows', type=int, nargs='+', default=[6])
+  ap.add_argument('--edge', type=int, nargs='+', default=[1])
   ap.add_argument('--rounds', type=int, default=3)
   ap.add_argument('--reps', type=int, default=20)
   ap.add_argument('--launches', type=int, default=1, help='launches per call (ping-pong through the program temporaries, as in a real run)')
+  ap.add_argument('--strategy', default='auto')
   ap.add_argument('--out', default=None)
   args = ap.parse_args()
   import torch
@@ -36,24 +40,35 @@ def main():
   shape = tuple(args.extent[::-1])
   configs = list(itertools.product(args.fuse, args.chunk, args.prefetch,
                                    args.waves, args.nt_store, args.nt_load,
-                                   args.xcd))
+                                   args.xcd, args.vec, args.tile_rows, args.edge))
   progs = []
   stream = torch.cuda.current_stream().cuda_stream
-  for fuse, chunk, pf, waves, nts, ntl, xcd in configs:
+  for fuse, chunk, pf, waves, nts, ntl, xcd, vec, trows, edge in configs:
     st = core.from_file(args.soda, iterate=fuse * args.launches)
     wx, wy = map(int, waves.split('x'))
-    opts = lower.LowerOptions(fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk,
+    opts = lower.LowerOptions(strategy=args.strategy, fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk,
                               prefetch=pf, waves_x=wx, waves_y=wy,
                               nt_store=bool(nts), nt_load=bool(ntl),
-                              xcd_swizzle=bool(xcd))
+                              xcd_swizzle=bool(xcd), vec=vec if vec > 0 else None,
+                              tile_rows=trows, edge_loads=bool(edge))
     try:
       progs.append((runtime.Program(st, opts, extent=args.extent), st, fuse))
     except Exception as e:  # noqa
       print('skip', fuse, chunk, pf, waves, str(e)[:200])
       progs.append(None)
   st0 = core.from_file(args.soda)
-  ins = [torch.rand(shape, device=dev, dtype=torch.float32) for _ in st0.input_names]
-  outs = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in st0.output_names]
+  tdt = {'float32': torch.float32, 'float64': torch.float64, 'uint16': torch.int16,
+         'int16': torch.int16, 'int32': torch.int32, 'uint8': torch.uint8}
+  def mk(t, rand):
+    dt = tdt[t.np_name]
+    if rand and dt.is_floating_point:
+      return torch.rand(shape, device=dev, dtype=dt)
+    if rand:
+      return torch.randint(0, 30000, shape, device=dev, dtype=dt)
+    return torch.empty(shape, device=dev, dtype=dt)
+  ins = [mk(t, True) for t in st0.input_types]
+  outs = [mk(t, False) for t in st0.output_types]
+  bytes_cell = sum(t.size_in_bytes for t in st0.input_types) + sum(t.size_in_bytes for t in st0.output_types)
   times = {i: [] for i in range(len(configs))}
   for r in range(args.rounds):
     for i, item in enumerate(progs):
@@ -80,8 +95,8 @@ def main():
     best = min(times[i]); med = sorted(times[i])[len(times[i]) // 2]
     fuse = cfg[0]
     rows.append(dict(fuse=fuse, chunk=cfg[1], prefetch=cfg[2], waves=cfg[3],
-                     nt_store=cfg[4], nt_load=cfg[5], xcd=cfg[6], ms_min=best,
-                     ms_med=med, GBs=cells * 8 / best / 1e6,
+                     nt_store=cfg[4], nt_load=cfg[5], xcd=cfg[6], vec=cfg[7], tile_rows=cfg[8], edge=cfg[9], ms_min=best,
+                     ms_med=med, GBs=cells * bytes_cell / best / 1e6,
                      Gcell_iters=cells * fuse / best / 1e6))
   rows.sort(key=lambda r: (r['fuse'], r['ms_min']))
   for r in rows:
