@@ -43,8 +43,9 @@ def parse_args():
                   help='iterations fused per launch (temporal blocking); the '
                   'first value is the dominant pass, the others serve the '
                   'remainder of iterate')
-  ap.add_argument('--chunk-rows', type=int, default=64)
-  ap.add_argument('--prefetch', type=int, default=2)
+  ap.add_argument('--chunk-rows', type=int, default=None,
+                  help='rows per wave; default: sized per kernel and GPU')
+  ap.add_argument('--prefetch', type=int, default=None)
   ap.add_argument('--waves-x', type=int, default=1)
   ap.add_argument('--waves-y', type=int, default=1)
   ap.add_argument('--strategy', default='auto')
@@ -82,9 +83,13 @@ def cpu_baseline(stencil, extent, target_seconds):
   cells = 1
   for e in extent:
     cells *= e
+  orc.run(a, iterate=1)    # first touch: page faults, thread pool
   t0 = time.time()
-  orc.run(a, iterate=2)
-  probe = (time.time() - t0) / 2
+  orc.run(a, iterate=4)
+  t4 = time.time() - t0
+  t0 = time.time()
+  orc.run(a, iterate=20)
+  probe = max(1e-4, (time.time() - t0 - t4) / 16)   # per iteration, net of setup
   iters = int(max(2, min(2000, target_seconds / max(probe, 1e-6))))
   t0 = time.time()
   orc.run(a, iterate=iters)

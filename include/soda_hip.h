@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 1
+#define SODA_HIP_ABI_VERSION 2
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
 #define SODA_HIP_MAX_KERNELS 32
@@ -75,6 +75,10 @@ typedef struct soda_hip_kargs {
   int64_t stride[SODA_HIP_MAX_DIM];    /* in elements; dimension 0 fastest */
   int32_t extent[SODA_HIP_MAX_DIM];    /* cells per dimension */
   int32_t ntile[SODA_HIP_MAX_DIM];     /* blocks per dimension; grid.x = product */
+  int32_t tile[SODA_HIP_MAX_DIM];      /* cells one block owns (the kernel
+                                          descriptor's tile: chunk lengths are
+                                          run-time values, tuned per GPU/extent
+                                          without recompiling) */
 } soda_hip_kargs_t;
 
 typedef struct soda_hip_kernel_desc {

@@ -38,7 +38,9 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-vec', type=int, dest='hip_vec', metavar='V',
                       help='cells per lane per row (default: 16 bytes worth)')
   parser.add_argument('--hip-chunk-rows', type=int, dest='hip_chunk_rows',
-                      default=64, help='rows one wavefront marches over')
+                      default=None, help='rows one wavefront marches over '
+                      '(default: sized at load time so the grid fills the GPU '
+                      'in one round of waves)')
   parser.add_argument('--hip-prefetch', type=int, dest='hip_prefetch',
                       default=None, help='input rows loaded ahead of use')
   parser.add_argument('--hip-tile-rows', type=int, dest='hip_tile_rows',

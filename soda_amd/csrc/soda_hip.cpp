@@ -291,6 +291,7 @@ static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
   int64_t blocks = 1;
   for (int i = 0; i < SODA_HIP_MAX_DIM; ++i) {
     int32_t t = i < p->plan.dim ? d.tile[i] : 1;
+    args.tile[i] = t;
     args.ntile[i] = (args.extent[i] + t - 1) / t;
     blocks *= args.ntile[i];
   }

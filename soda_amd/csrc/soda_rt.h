@@ -33,6 +33,7 @@ struct soda_hip_kargs_t {
   int64_t stride[4];
   int32_t extent[4];
   int32_t ntile[4];
+  int32_t tile[4];
 };
 
 #define SODA_DEV static __device__ inline __attribute__((always_inline))

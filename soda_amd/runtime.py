@@ -38,7 +38,7 @@ MAX_KERNELS = 32
 MAX_PASSES = 8
 MAX_PASS_KERNELS = 16
 NAME_LEN = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KernelDesc(ctypes.Structure):
@@ -255,6 +255,83 @@ def make_plan(mod: lower.Module) -> Plan:
   return plan
 
 
+def kernel_resources(code: bytes) -> Dict[str, dict]:
+  """Per-kernel register/LDS use read from the code object's AMDGPU metadata
+  note (msgpack): {kernel name: {'vgpr': n, 'sgpr': n, 'lds': bytes,
+  'scratch': bytes}}.  Returns {} if the note cannot be read."""
+  import struct
+  try:
+    import msgpack
+    if code[:4] != b'\x7fELF':
+      return {}
+    shoff, = struct.unpack_from('<Q', code, 0x28)
+    shentsize, shnum = struct.unpack_from('<HH', code, 0x3A)
+    for i in range(shnum):
+      off = shoff + i * shentsize
+      sh_type, = struct.unpack_from('<I', code, off + 4)
+      if sh_type != 7:       # SHT_NOTE
+        continue
+      sec_off, sec_size = struct.unpack_from('<QQ', code, off + 0x18)
+      pos, end = sec_off, sec_off + sec_size
+      while pos + 12 <= end:
+        namesz, descsz, ntype = struct.unpack_from('<III', code, pos)
+        pos += 12
+        name = code[pos:pos + namesz].rstrip(b'\0')
+        pos += (namesz + 3) & ~3
+        desc = code[pos:pos + descsz]
+        pos += (descsz + 3) & ~3
+        if name == b'AMDGPU' and ntype == 32:     # NT_AMDGPU_METADATA
+          meta = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+          out = {}
+          for k in meta.get('amdhsa.kernels', []):
+            out[k['.name']] = dict(
+                vgpr=k.get('.vgpr_count', 0) + 0, sgpr=k.get('.sgpr_count', 0),
+                agpr=k.get('.agpr_count', 0),
+                lds=k.get('.group_segment_fixed_size', 0),
+                scratch=k.get('.private_segment_fixed_size', 0))
+          return out
+  except Exception:
+    return {}
+  return {}
+
+
+NUM_CUS = 256          # MI355X: 8 XCDs x 32 CUs, 4 SIMDs each
+MAX_WAVES_PER_SIMD = 8
+
+
+def waves_per_simd(vgprs: int) -> int:
+  """Occupancy the register file allows (MI355X_MICROARCH.md, Register
+  files: 512 VGPRs per lane per SIMD, allocation granule 8)."""
+  alloc = max(8, -(-vgprs // 8) * 8)
+  return max(1, min(MAX_WAVES_PER_SIMD, 512 // alloc))
+
+
+def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
+                vgprs: int, extent: Sequence[int]) -> int:
+  """Length (cells along the marched dimension) one wave should own so that
+  the whole grid is resident at once and every SIMD holds the same number of
+  waves.  Model (checked by tools/sweep.py --chunk, profiles/r01_sweeps.md):
+  a SIMD's waves share its issue slots, so run time ~ waves per SIMD x
+  (chunk + warm-up); for a fixed amount of work that is minimal with ONE round
+  of waves, as long as the chunk stays several times the warm-up."""
+  axis = tune['axis']
+  others = 1
+  for d in range(len(extent)):
+    if d != axis:
+      others *= -(-extent[d] // tile[d])
+  waves_per_block = max(1, block_threads // 64)
+  slots = NUM_CUS * 4 * waves_per_simd(vgprs) // waves_per_block  # blocks
+  blocks_along = max(1, slots // max(1, others))
+  per_block = -(-extent[axis] // blocks_along)
+  per_wave = -(-per_block // tune['waves_along'])
+  per_wave = max(per_wave, 4 * tune['warm'], 64)
+  per_wave = min(per_wave, extent[axis])
+  # even out: the same number of chunks, all of (nearly) equal length
+  n = -(-extent[axis] // (per_wave * tune['waves_along']))
+  per_wave = -(-extent[axis] // (n * tune['waves_along']))
+  return max(1, per_wave)
+
+
 def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
   """Cells per lane per row: 16 bytes' worth, reduced until it divides the
   row length (rows must stay 16-byte aligned for the vector loads)."""
@@ -280,6 +357,10 @@ class Program:
     self.plan = make_plan(self.module)
     self.code = compile_source(self.module.source,
                                '%s.hip' % stencil.app_name)
+    self.resources = kernel_resources(self.code)
+    self.tuned_for = None
+    if extent is not None:
+      self.tune(extent)
     self._lib = library()
     self._handle = ctypes.c_void_p()
     check(
@@ -287,6 +368,25 @@ class Program:
                                           ctypes.byref(self.plan), device,
                                           ctypes.byref(self._handle)),
         'loading `%s` on GPU %d' % (stencil.app_name, device))
+
+  # -- launch geometry ------------------------------------------------------
+  def tune(self, extent: Sequence[int]) -> None:
+    """Sizes every marching kernel's chunk for `extent` on this GPU (plan
+    only; the code object is unchanged).  Must precede program creation."""
+    for i, k in enumerate(self.module.kernels):
+      if not k.tune or k.tune.get('fixed'):
+        continue
+      res = self.resources.get(k.name)
+      if not res:
+        continue
+      axis = k.tune['axis']
+      tile = list(k.tile)
+      per_wave = tuned_chunk(k.tune, tile, k.block[0] * k.block[1] * k.block[2],
+                             res['vgpr'], extent)
+      tile[axis] = per_wave * k.tune['waves_along']
+      k.tile = tuple(tile)
+      self.plan.kernels[i].tile[axis] = tile[axis]
+    self.tuned_for = tuple(extent)
 
   # -- lifecycle -----------------------------------------------------------
   def close(self) -> None:

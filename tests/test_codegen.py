@@ -35,7 +35,7 @@ def test_struct_mirrors_match(built):
   from soda_amd import runtime
   lib = runtime.library()   # also runs the built-in layout check
   assert lib.soda_hip_abi_version() == runtime.ABI_VERSION
-  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 4 * 4 + 4 * 4
+  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 4 * 4 + 4 * 4 + 4 * 4
   assert lib.soda_hip_sizeof(3) == ctypes.sizeof(runtime.Plan)
   assert lib.soda_hip_sizeof(99) == 0
   assert lib.soda_hip_status_string(5) == b'no usable GPU'
@@ -46,6 +46,7 @@ def test_kargs_struct_in_device_runtime_matches_header():
   rt = lower.runtime_text()
   assert 'void* buf[16];' in rt and 'int64_t stride[4];' in rt
   assert 'int32_t extent[4];' in rt and 'int32_t ntile[4];' in rt
+  assert 'int32_t tile[4];' in rt
 
 
 ALL = sorted(f for f in os.listdir(SODA_DIR) if f.endswith('.soda')) + [
@@ -111,6 +112,27 @@ def test_march3d_geometry_for_heat3d():
   # in registers; 64 planes marched per wave
   assert p.kind == 'march3d' and k.tile[:3] == (256, 4, 64)
   assert p.traffic_model['rows_in'] == 6 and p.traffic_model['edge'] == (1, 1)
+
+
+def test_chunk_is_sized_from_the_code_objects_registers(built, tmp_path):
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  opts = lower.LowerOptions(fuse=(12,), vec=4)
+  mod = lower.lower(stencil, opts)
+  code = runtime.compile_source(mod.source, 'j.hip', cache_dir=str(tmp_path))
+  res = runtime.kernel_resources(code)
+  assert set(res) == {k.name for k in mod.kernels}
+  for k in mod.kernels:
+    assert 16 <= res[k.name]['vgpr'] <= 256 and res[k.name]['scratch'] == 0
+    chunk = runtime.tuned_chunk(k.tune, k.tile, 64, res[k.name]['vgpr'],
+                                (8192, 8192))
+    waves = -(-8192 // k.tile[0]) * -(-8192 // chunk)
+    slots = 1024 * runtime.waves_per_simd(res[k.name]['vgpr'])
+    assert chunk >= 64 and waves <= max(slots, 8192 // 64 * 36)
+  assert runtime.waves_per_simd(64) == 8 and runtime.waves_per_simd(65) == 7
+  assert runtime.waves_per_simd(128) == 4 and runtime.waves_per_simd(167) == 3
+  assert runtime.waves_per_simd(300) == 1
 
 
 def test_vector_width_follows_row_length():

@@ -46,7 +46,7 @@ def main():
   for fuse, chunk, pf, waves, nts, ntl, xcd, vec, trows, edge in configs:
     st = core.from_file(args.soda, iterate=fuse * args.launches)
     wx, wy = map(int, waves.split('x'))
-    opts = lower.LowerOptions(strategy=args.strategy, fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk,
+    opts = lower.LowerOptions(strategy=args.strategy, fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk if chunk > 0 else None,
                               prefetch=pf, waves_x=wx, waves_y=wy,
                               nt_store=bool(nts), nt_load=bool(ntl),
                               xcd_swizzle=bool(xcd), vec=vec if vec > 0 else None,
