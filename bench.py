@@ -121,9 +121,15 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   tdist = None
-  if world > 1:
+  force_dist = bool(os.environ.get('SODA_BENCH_FORCE_DIST'))  # 1-rank rehearsal
+  if world > 1 or force_dist:
     import torch.distributed as tdist
-    tdist.init_process_group('nccl', device_id=dev)
+    if force_dist and 'RANK' not in os.environ:
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      os.environ.setdefault('MASTER_PORT', '29531')
+      tdist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    else:
+      tdist.init_process_group('nccl', device_id=dev)
 
   stencil = core.from_file(args.soda, iterate=args.iterate)
   extent = list(args.extent)
@@ -131,7 +137,7 @@ def main():
     extent[-1] *= world
   fuses = sorted({f for f in args.fuse if f >= 1}, reverse=True)
   fuse = fuses[0]
-  ex = args.exchange_every
+  ex = args.exchange_every if world > 1 else args.iterate
   if fuse > 1:
     ex = max(fuse, ex // fuse * fuse)
   slab = sdist.Slab(stencil, extent, world, rank, ex)
@@ -155,7 +161,7 @@ def main():
   np_dtypes = {'float32': torch.float32, 'float64': torch.float64,
                'uint16': torch.int16, 'int16': torch.int16,
                'int32': torch.int32}
-  a_bufs, b_bufs = [], []
+  a_bufs, b_bufs, c_bufs = [], [], []
   for name, t in zip(stencil.input_names, stencil.input_types):
     dt = np_dtypes[t.np_name]
     if dt.is_floating_point:
@@ -166,6 +172,8 @@ def main():
     a_bufs.append(full[slab.begin:slab.end].clone())
     del full
     b_bufs.append(torch.empty_like(a_bufs[-1]))
+    if world > 1:
+      c_bufs.append(torch.empty_like(a_bufs[-1]))
   torch.cuda.synchronize()
 
   def step_fn(dst, src, lext, iters):
@@ -174,10 +182,11 @@ def main():
 
   def one_step():
     # a step always starts from the same buffers; ghosts of a_bufs are fresh
-    return sdist.run(slab, a_bufs, b_bufs, step_fn, args.iterate, tdist)
+    return sdist.run(slab, a_bufs, b_bufs, c_bufs or b_bufs, step_fn,
+                     args.iterate, tdist)
 
   def barrier():
-    if world > 1:
+    if tdist is not None:
       tdist.barrier()
 
   launches_per_step = 0
@@ -192,7 +201,8 @@ def main():
     _orig_step(dst, src, lext, iters)
     launches_per_step += prog.last_launches()[0]
 
-  sdist.run(slab, a_bufs, b_bufs, counting_step, args.iterate, tdist)
+  sdist.run(slab, a_bufs, b_bufs, c_bufs or b_bufs, counting_step,
+            args.iterate, tdist)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
@@ -203,7 +213,7 @@ def main():
   barrier()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
-  if world > 1:
+  if tdist is not None:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -330,7 +340,7 @@ def main():
 
   if rank == 0:
     print(json.dumps(result))
-  if world > 1:
+  if tdist is not None:
     tdist.destroy_process_group()
 
 

@@ -62,13 +62,16 @@ SODA_DEV auto soda_abs(A a) -> decltype(+a) {
 // ---- whole-wave lane shifts (DPP) -----------------------------------------
 // soda_lane_dn(v): lane i receives lane i-1's v (lane 0 receives 0).
 // soda_lane_up(v): lane i receives lane i+1's v (lane 63 receives 0).
+// bound_ctrl:1 = lanes without a source lane read 0, so no `old` register has
+// to be materialised (saves one v_mov per shift; the shift itself fuses into
+// the consuming v_add_f32 as a DPP operand)
 SODA_DEV int soda_dpp_shr1(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf,
-                                     false);
+                                     true);
 }
 SODA_DEV int soda_dpp_shl1(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf,
-                                     false);
+                                     true);
 }
 
 // same, but the lane with no source (0 resp. 63) receives ITS OWN `edge`

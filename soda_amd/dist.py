@@ -99,14 +99,17 @@ def exchange(slab: Slab, tensors: Sequence, dist_module, group=None) -> None:
       req.wait()
 
 
-def run(slab: Slab, bufs_a: Sequence, bufs_b: Sequence,
+def run(slab: Slab, src: Sequence, work_a: Sequence, work_b: Sequence,
         step: Callable[[Sequence, Sequence, Tuple[int, ...], int], None],
         iterate: int, dist_module, group=None, ghosts_fresh: bool = True):
-  """Advances the program `iterate` iterations.  `bufs_a` hold the current
-  state (own rows + ghosts), `bufs_b` are same-shaped work arrays; returns the
-  list that holds the result.  `ghosts_fresh`: ghosts of `bufs_a` already hold
-  neighbour data (true right after slicing them out of the global input)."""
-  cur, nxt = list(bufs_a), list(bufs_b)
+  """Advances the program `iterate` iterations.  `src` holds the inputs (own
+  rows + ghosts) and is never written; `work_a` / `work_b` are same-shaped
+  work arrays the state ping-pongs through (`work_b` is only touched when more
+  than one exchange interval is needed).  Returns the list that holds the
+  result.  `ghosts_fresh`: the ghosts of `src` already hold neighbour data
+  (true right after slicing them out of the global input)."""
+  cur, nxt = list(src), list(work_a)
+  spare = list(work_b)
   done = 0
   fresh = ghosts_fresh
   while done < iterate:
@@ -114,7 +117,10 @@ def run(slab: Slab, bufs_a: Sequence, bufs_b: Sequence,
     if not fresh:
       exchange(slab, cur, dist_module, group)
     step(nxt, cur, slab.local_extent, k)
-    cur, nxt = nxt, cur
+    if done == 0:
+      cur, nxt = nxt, spare          # src drops out of the rotation
+    else:
+      cur, nxt = nxt, cur
     done += k
     fresh = False
   return cur

@@ -43,7 +43,9 @@ def _worker(rank, world, port, name, extent, iterate, every, out_dir):
       full[n] = rng.integers(0, 60000, tuple(extent[::-1])).astype(t.np_name)
   cur = [torch.from_numpy(full[n][slab.begin:slab.end].copy())
          for n in stencil.input_names]
-  nxt = [torch.empty_like(t) for t in cur]
+  keep = [t.clone() for t in cur]
+  work_a = [torch.empty_like(t) for t in cur]
+  work_b = [torch.empty_like(t) for t in cur]
 
   def step(dst, src, lext, iters):
     ins = {n: s.numpy() for n, s in zip(stencil.input_names, src)}
@@ -51,7 +53,8 @@ def _worker(rank, world, port, name, extent, iterate, every, out_dir):
     for d, o in zip(dst, stencil.output_names):
       d.copy_(torch.from_numpy(outs[o]))
 
-  res = sdist.run(slab, cur, nxt, step, iterate, tdist)
+  res = sdist.run(slab, cur, work_a, work_b, step, iterate, tdist)
+  assert all(torch.equal(a, b) for a, b in zip(cur, keep)), 'inputs written'
   own = [r[slab.ghost_lo:slab.ghost_lo + slab.own_rows].numpy() for r in res]
   np.save(os.path.join(out_dir, 'rank%d.npy' % rank), own[0])
   tdist.barrier()

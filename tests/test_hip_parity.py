@@ -154,6 +154,52 @@ def test_row_length_picks_vector_width(built, vec_extent):
   _check(stencil, vec_extent, lower.LowerOptions(fuse=(2,)))
 
 
+@pytest.mark.parametrize('name,extent,iterate', [
+    ('jacobi2d.soda', (8, 8), 1), ('jacobi2d.soda', (5, 7), 2),
+    ('jacobi2d.soda', (260, 9), 3), ('jacobi2d.soda', (256, 3), 1),
+    ('jacobi2d.soda', (4, 300), 1), ('blur.soda', (16, 5), 1),
+    ('blur.soda', (3, 3), 1), ('skew2d.soda', (12, 6), 1),
+    ('heat3d.soda', (8, 8, 8), 2), ('heat3d.soda', (260, 5, 4), 1),
+    ('heat3d.soda', (516, 7, 70), 1), ('jacobi3d.soda', (12, 3, 9), 1),
+])
+def test_small_and_odd_extents(built, name, extent, iterate):
+  """Grids smaller than one strip / chunk / tile, and not multiples of them."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  lo, hi = stencil.valid_box(extent)
+  if not all(h > l for l, h in zip(lo, hi)):
+    pytest.skip('valid box is empty')
+  _check(stencil, extent, lower.LowerOptions(fuse=(2,)))
+
+
+def test_one_dimensional_program(built):
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_text(
+      'kernel: smooth1d\nburst width: 64\nunroll factor: 2\niterate: 3\n'
+      'input float: a\n'
+      'output float: b(0) = (a(-1) + a(0) * 2.0f + a(1)) * 0.25f')
+  _check(stencil, (1000,), lower.LowerOptions())
+
+
+def test_explicit_chunk_and_wave_shapes(built):
+  """Non-default launch geometry gives the same bits."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=5)
+  for kw in (dict(chunk_rows=7, waves_x=2, waves_y=2),
+             dict(chunk_rows=300, prefetch=1),
+             dict(chunk_rows=16, prefetch=4, nt_store=True, nt_load=False,
+                  xcd_swizzle=False, edge_loads=False),
+             dict(warm_guards=True), dict(vec=2), dict(vec=1, chunk_rows=33)):
+    _check(stencil, (1000, 200), lower.LowerOptions(fuse=(3,), **kw))
+  h = core.from_file(soda_path('heat3d.soda'), iterate=2)
+  for kw in (dict(tile_rows=1), dict(tile_rows=6, chunk_rows=5),
+             dict(edge_loads=False, prefetch=2)):
+    _check(h, (300, 20, 24), lower.LowerOptions(**kw))
+
+
 def test_blur_reference_init_closed_form(built):
   """blur on the reference harness's p+q input is p+q+2 (SURVEY 8c KAT)."""
   from soda_amd import core, runtime
