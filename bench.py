@@ -49,9 +49,18 @@ def parse_args():
   ap.add_argument('--waves-x', type=int, default=1)
   ap.add_argument('--waves-y', type=int, default=1)
   ap.add_argument('--strategy', default='auto')
-  ap.add_argument('--exchange-every', type=int, default=24,
-                  help='iterations between halo exchanges (N > 1)')
+  ap.add_argument('--exchange-every', type=int, default=0,
+                  help='iterations between halo exchanges (N > 1); 0 = auto: '
+                  'as many as keep the ghost rows below half a slab -- for '
+                  'iterate=100 on 8192 rows that is all 100, i.e. the halo is '
+                  'distributed once with the input, as the reference host '
+                  'replicates it between tiles, and no exchange is needed')
   ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
+  ap.add_argument('--emulate-slab', type=int, default=0, metavar='N',
+                  help='(rehearsal on one GPU) run the middle rank\'s slab of '
+                  'an N-GPU run; only valid when no exchange is needed; the '
+                  'JSON value is then what the N-GPU job would score if every '
+                  'rank ran at this speed')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-single-iter', action='store_true')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
@@ -112,6 +121,7 @@ def main():
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
+  emulate = args.emulate_slab if world == 1 else 0
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
@@ -137,10 +147,25 @@ def main():
     extent[-1] *= world
   fuses = sorted({f for f in args.fuse if f >= 1}, reverse=True)
   fuse = fuses[0]
-  ex = args.exchange_every if world > 1 else args.iterate
-  if fuse > 1:
-    ex = max(fuse, ex // fuse * fuse)
-  slab = sdist.Slab(stencil, extent, world, rank, ex)
+  geo_world, geo_rank = (emulate, emulate // 2) if emulate > 1 else (world, rank)
+  if geo_world == 1:
+    ex = args.iterate
+  elif args.exchange_every > 0:
+    ex = args.exchange_every
+    if fuse > 1:
+      ex = max(fuse, ex // fuse * fuse)
+  else:
+    lo_r, hi_r = stencil.radius
+    reach = max(1, -lo_r[-1] + hi_r[-1])
+    own = extent[-1] // geo_world
+    ex = max(1, min(args.iterate, own // (2 * reach)))
+    if fuse > 1 and ex < args.iterate:
+      ex = max(fuse, ex // fuse * fuse)
+  slab = sdist.Slab(stencil, extent, geo_world, geo_rank, ex)
+  if emulate > 1:
+    if sdist.rounds(args.iterate, ex) > 1:
+      raise SystemExit('--emulate-slab needs an exchange-free schedule')
+    slab.world = 1   # no peers: exchange() is a no-op
   local_extent = slab.local_extent
 
   def options(fuse_list):
@@ -291,6 +316,7 @@ def main():
       'metric': 'stencil cells*iters/s, %s %s iterate=%d' %
                 (stencil.app_name, 'x'.join(map(str, extent)), args.iterate),
       'value': value, 'unit': 'cells*iters/s', 'n_gpus': world,
+      **({'emulated_n_gpus': emulate} if emulate > 1 else {}),
       'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
       'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
@@ -302,8 +328,11 @@ def main():
                        'x'.join(map(str, extent)), args.iterate),
           'kernel_family': passes[0].kind if passes else '?',
           'fused_iterations_per_launch': fuse,
-          'decomposition': 'slabs along dim %d, halo exchange every %d iters'
-                           % (stencil.dim - 1, ex) if world > 1 else 'none',
+          'decomposition': ('slabs along dim %d, %d ghost rows per side, '
+                            '%d halo exchange(s) per step' %
+                            (stencil.dim - 1, slab.ghost_hi or slab.ghost_lo,
+                             sdist.rounds(args.iterate, ex) - 1))
+                           if world > 1 else 'none',
           'launches_per_step': launches_per_step,
           'passes': [p.fused_iters for p in prog.module.sorted_passes()],
       },

@@ -308,28 +308,47 @@ def waves_per_simd(vgprs: int) -> int:
 
 def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
                 vgprs: int, extent: Sequence[int]) -> int:
-  """Length (cells along the marched dimension) one wave should own so that
-  the whole grid is resident at once and every SIMD holds the same number of
-  waves.  Model (checked by tools/sweep.py --chunk, profiles/r01_sweeps.md):
-  a SIMD's waves share its issue slots, so run time ~ waves per SIMD x
-  (chunk + warm-up); for a fixed amount of work that is minimal with ONE round
-  of waves, as long as the chunk stays several times the warm-up."""
+  """Length (cells along the marched dimension) one wave should own.
+
+  Model, fitted to tools/sweep.py --chunk runs (profiles/r01_sweeps.md): the
+  waves of a launch are dealt evenly over the 1024 SIMDs, a SIMD's waves share
+  its issue slots, and every wave pays `warm` pipeline warm-up steps on top of
+  its chunk, so
+
+      time ~ k * eff(k) * (chunk + warm),  k = max(k_min, ceil(waves / 1024))
+
+  with waves = (strips x tiles in the other dimensions) x ceil(extent/chunk).
+  k_min: one wave alone on a SIMD issues at half rate (2), and a kernel that
+  fuses few iterations is latency-bound and wants >= 4 waves per SIMD in
+  flight.  The chunk minimising this is taken (ties: the longer chunk, i.e.
+  less redundant traffic).  Examples on 8192 columns: 8192 rows, T=12 -> ~100
+  rows (one round of 3 waves/SIMD); a 1224-row slab (8-GPU run) -> ~32 rows."""
   axis = tune['axis']
+  n = extent[axis]
   others = 1
   for d in range(len(extent)):
     if d != axis:
       others *= -(-extent[d] // tile[d])
   waves_per_block = max(1, block_threads // 64)
-  slots = NUM_CUS * 4 * waves_per_simd(vgprs) // waves_per_block  # blocks
-  blocks_along = max(1, slots // max(1, others))
-  per_block = -(-extent[axis] // blocks_along)
-  per_wave = -(-per_block // tune['waves_along'])
-  per_wave = max(per_wave, 4 * tune['warm'], 64)
-  per_wave = min(per_wave, extent[axis])
-  # even out: the same number of chunks, all of (nearly) equal length
-  n = -(-extent[axis] // (per_wave * tune['waves_along']))
-  per_wave = -(-extent[axis] // (n * tune['waves_along']))
-  return max(1, per_wave)
+  along = max(1, tune['waves_along'])
+  across = waves_per_block // along      # waves of a block side by side
+  warm = tune['warm']
+  k_min = 4 if warm <= 12 else 2
+  simds = NUM_CUS * 4
+  best = None
+  for chunk in range(min(n, 8), n + 1):
+    chunks = -(-n // chunk)
+    blocks = others * -(-chunks // along)
+    waves = blocks * waves_per_block
+    k = max(k_min, -(-waves // simds))
+    # a lone wave issues at half rate; two waves still leave dependency
+    # bubbles (measured ~20 % on the VALU-bound fused kernels)
+    cost = k * (2.0 if k == 1 else 1.2 if k == 2 else 1.0) * (chunk + warm)
+    if best is None or cost < best[0] or (cost == best[0] and chunk > best[1]):
+      best = (cost, chunk)
+  chunk = best[1]
+  chunks = -(-n // chunk)
+  return max(1, -(-n // chunks))          # same count, equal lengths
 
 
 def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
