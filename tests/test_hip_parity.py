@@ -200,6 +200,37 @@ def test_explicit_chunk_and_wave_shapes(built):
     _check(h, (300, 20, 24), lower.LowerOptions(**kw))
 
 
+@pytest.mark.parametrize('name,iterate,fuse', [
+    ('blur.soda', 3, (2,)), ('blur.soda', 4, (4,)), ('seidel2d.soda', 7, (3,)),
+    ('jacobi3d.soda', 3, ()), ('heat3d.soda', 5, ()),
+])
+def test_iterated_multi_stage_and_3d(built, name, iterate, fuse):
+  """Temporal blocking of a two-stage program (4 stages fused for blur x 2)
+  and iterated 3-D programs."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  extent = (640, 200) if stencil.dim == 2 else (300, 24, 40)
+  _check(stencil, extent, lower.LowerOptions(fuse=fuse), oracle='c')
+
+
+def test_sodac_hip_backend_runs(built):
+  """`sodac file.soda --hip-backend`: parse, JIT, run on the GPU, JSON out."""
+  import json
+  import subprocess
+  import sys
+  from conftest import ROOT
+  r = subprocess.run([sys.executable, '-m', 'soda_amd.sodac',
+                      soda_path('blur.soda'), '--hip-backend', '--hip-extent',
+                      '2000', '64'], cwd=ROOT, capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr
+  out = json.loads(r.stdout.strip().splitlines()[-1])
+  assert out['kernel'] == 'blur' and out['extent'] == [2000, 64]
+  # ramp input p+q -> blur_y = p+q+2 on [0,1998) x [0,62), zero elsewhere
+  q, p = np.indices((64, 2000))
+  assert out['checksum']['blur_y'] == float((p + q + 2)[:62, :1998].sum())
+
+
 def test_blur_reference_init_closed_form(built):
   """blur on the reference harness's p+q input is p+q+2 (SURVEY 8c KAT)."""
   from soda_amd import core, runtime
@@ -274,7 +305,9 @@ def test_device_entry_and_errors(built):
 
 @pytest.mark.parametrize('name,extent,iterate,fuse', [
     ('jacobi2d.soda', (8192, 8192), 12, (4,)),
-    ('blur.soda', (16384, 16384), 1, ()),
+    ('jacobi2d.soda', (8192, 8192), 100, (12, 4)),     # BASELINE config 1/2
+    ('blur.soda', (16384, 16384), 1, ()),              # BASELINE config 3
+    ('heat3d.soda', (512, 512, 512), 6, ()),           # BASELINE config 4 grid
 ])
 def test_full_size_properties(built, name, extent, iterate, fuse):
   """BASELINE-sized grids: compare against the multi-threaded C oracle on the
