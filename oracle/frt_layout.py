@@ -1,0 +1,117 @@
+"""CPU restatement of the reference HOST's wire layout -- TEST INFRASTRUCTURE.
+
+Only tests/ may import this.  Restates, in numpy, what the reference's generated
+C++ host does around the kernel call: sizing (reference
+src/soda/codegen/frt/host.py:124-178), scatter of the caller's array into
+tiled, burst-aligned, bank-interleaved streams (:181-249) and gather of each
+output's valid region (:340-427).  It lets tests drive
+soda_amd.stream.StreamProgram exactly the way the unmodified reference host
+would.  Only single-input programs are covered (`produce_offset` of further
+inputs comes out of the reference's ILP), and tests use one tile per dimension:
+for several tiles the reference scatters with stride `tile - kStencilDim`
+(:225-227) but gathers with `tile - kStencilDim + 1` (:389-391)."""
+import itertools
+
+import numpy as np
+
+from soda_amd import util
+from soda_amd.stream import WireLayout
+
+
+def _tile_iter(layout):
+  return itertools.product(*[range(c) for c in layout.tile_count])
+
+
+def _actual(layout, d, t):
+  st = layout.stencil
+  if t == layout.tile_count[d] - 1:
+    return layout.extent[d] - (st.tile_size[d] - layout.stencil_dim[d] + 1) * t
+  return st.tile_size[d]
+
+
+def alloc(layout, names):
+  st = layout.stencil
+  table = st.symbol_table
+  out = {}
+  for n in names:
+    nb = layout.bank_count[n]
+    out[n] = [np.zeros(layout.buf_elems[n] // nb, np.dtype(table[n].np_name))
+              for _ in range(nb)]
+  return out
+
+
+def scatter(layout, inputs):
+  """host.py:181-249."""
+  st = layout.stencil
+  dim = st.dim
+  tile = st.tile_size
+  banks = alloc(layout, st.input_names)
+  for tidx in _tile_iter(layout):
+    tile_lin = 0
+    mul = 1
+    for d in range(dim - 1):
+      tile_lin += tidx[d] * mul
+      mul *= layout.tile_count[d]
+    sizes = [_actual(layout, d, tidx[d]) for d in range(dim - 1)]
+    grids = np.meshgrid(*[np.arange(s) for s in sizes] +
+                        [np.arange(layout.extent[dim - 1])], indexing='ij')
+    off_in_tile = np.zeros_like(grids[0])
+    mul = 1
+    for d in range(dim):
+      off_in_tile = off_in_tile + grids[d] * mul
+      if d < dim - 1:
+        mul *= tile[d]
+    orig = [tidx[d] * (tile[d] - layout.stencil_dim[d]) + grids[d]
+            for d in range(dim - 1)] + [grids[dim - 1]]
+    tiled = tile_lin * layout.aligned_per_tile_i + off_in_tile
+    for name in st.input_names:
+      nb = layout.bank_count[name]
+      vals = inputs[name][tuple(orig[::-1])]
+      for b in range(nb):
+        sel = (tiled % nb) == b
+        banks[name][b][(tiled[sel] // nb)] = vals[sel]
+  return banks
+
+
+def gather(layout, out_banks, outputs):
+  """host.py:340-427: only the valid region reaches the caller's arrays."""
+  st = layout.stencil
+  dim = st.dim
+  tile = st.tile_size
+  window = st.stencil_window_points(st.output_names[0])
+  off = [-min(p[d] for p in window) for d in range(dim)]
+  sdim = [max(p[d] for p in window) - min(p[d] for p in window) + 1
+          for d in range(dim)]
+  for tidx in _tile_iter(layout):
+    tile_lin = 0
+    mul = 1
+    for d in range(dim - 1):
+      tile_lin += tidx[d] * mul
+      mul *= layout.tile_count[d]
+    ranges = []
+    for d in range(dim - 1):
+      ranges.append(np.arange(max(0, off[d]), _actual(layout, d, tidx[d]) -
+                              max(0, sdim[d] - 1 - off[d])))
+    ranges.append(np.arange(max(0, off[dim - 1]), layout.extent[dim - 1] -
+                            max(0, sdim[dim - 1] - 1 - off[dim - 1])))
+    if any(len(r) == 0 for r in ranges):
+      continue
+    grids = np.meshgrid(*ranges, indexing='ij')
+    off_in_tile = np.zeros_like(grids[0])
+    mul = 1
+    for d in range(dim):
+      off_in_tile = off_in_tile + grids[d] * mul
+      if d < dim - 1:
+        mul *= tile[d]
+    orig = [tidx[d] * (tile[d] - layout.stencil_dim[d] + 1) + grids[d]
+            for d in range(dim - 1)] + [grids[dim - 1]]
+    for name in st.output_names:
+      nb = layout.bank_count[name]
+      tiled = (tile_lin * layout.aligned_per_tile_o + off_in_tile +
+               layout.stencil_offset[name])
+      vals = np.empty(tiled.shape, outputs[name].dtype)
+      for b in range(nb):
+        sel = (tiled % nb) == b
+        vals[sel] = out_banks[name][b][tiled[sel] // nb]
+      outputs[name][tuple(orig[::-1])] = vals
+  return outputs

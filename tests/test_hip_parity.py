@@ -333,3 +333,46 @@ def test_full_size_properties(built, name, extent, iterate, fuse):
       unfused = prog.run(inputs)
     for o in stencil.output_names:
       assert np.array_equal(got[o], unfused[o])
+
+
+STREAM_CASES = [
+    ('blur.soda', None, (2000, 20), None),
+    ('jacobi2d.soda', None, (32, 12), None),          # iterate 2, as shipped
+    ('jacobi2d.soda', None, (20, 9), None),           # narrower than the tile
+    ('heat3d.soda', None, (32, 32, 9), None),         # iterate 2, 3-D tiles
+    ('sobel2d.soda', None, (32, 8), None),            # three stages, int16
+    ('jacobi2d.soda', 'input dram 0.1 float: t1(32, *)', (32, 12),
+     'output dram 2.3 float:'),                       # two banks each side
+]
+
+
+@pytest.mark.parametrize('name,in_decl,extent,out_decl', STREAM_CASES)
+def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl):
+  """<app>_kernel(out banks, in banks, coalesced_data_num) on the
+  reference's tiled / burst-aligned / bank-interleaved streams, driven by a
+  restatement of the reference host's scatter and gather."""
+  import re
+  from soda_amd import core, stream
+  from oracle import frt_layout, numpy_oracle
+  text = open(soda_path(name)).read()
+  if in_decl:
+    text = re.sub(r'input dram \d+ float: t1\(32, \*\)', in_decl, text)
+    text = re.sub(r'output dram \d+ float:', out_decl, text)
+  stencil = core.from_text(text)
+  inputs = _inputs(stencil, extent, seed=5)
+  layout = stream.WireLayout(stencil, extent)
+  in_banks = frt_layout.scatter(layout, inputs)
+  out_banks = frt_layout.alloc(layout, stencil.output_names)
+  prog = stream.StreamProgram(stencil)
+  try:
+    prog.run_banked_host(out_banks, in_banks, layout.cycle_count)
+  finally:
+    prog.close()
+  got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(stencil.output_names, stencil.output_types)}
+  frt_layout.gather(layout, out_banks, got)
+  want = numpy_oracle.run(stencil, inputs)
+  for o in stencil.output_names:
+    assert np.array_equal(got[o], want[o]), o
+  lo, hi = stencil.valid_box(extent)
+  assert all(h > l for l, h in zip(lo, hi))

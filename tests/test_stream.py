@@ -1,0 +1,77 @@
+"""Wire-format logic on the CPU: layout numbers, linearisation,
+and the whole scatter -> 1-D stencil -> shift -> gather chain with the numpy
+oracle standing in for the GPU kernel (the GPU run is in test_hip_parity.py)."""
+import numpy as np
+import pytest
+
+from conftest import soda_path
+from soda_amd import core, stream
+
+
+def test_layout_numbers_match_the_reference_formulas():
+  blur = core.from_file(soda_path('blur.soda'))
+  lay = stream.WireLayout(blur, (2000, 1024))
+  # burst 256 bit / uint16 x 1 bank = 16 elements per cycle (frt/host.py:120)
+  assert lay.epc == {'input': 16, 'blur_y': 16}
+  assert lay.tile_count == [1] and lay.stencil_distance == 4002
+  assert lay.elem_count_per_tile == 2000 * 1024
+  assert lay.cycle_count == -(-(2000 * 1024 + 4002) // 16)
+  assert lay.stencil_offset == {'blur_y': 4002}
+  assert lay.buf_elems['input'] == 2000 * 1024 + 4016      # round_up(4002, 16)
+  j = core.from_file(soda_path('jacobi2d.soda'))            # iterate 2, tile 32
+  lay = stream.WireLayout(j, (32, 6))
+  assert lay.stencil_distance == 130 and lay.stencil_offset == {'t0': 64}
+  wide = stream.WireLayout(j, (100, 6))                     # > one tile wide
+  assert wide.tile_count == [(100 - 5) // (32 - 5 + 1) + 1]
+
+
+def test_linearize():
+  j = core.from_file(soda_path('jacobi2d.soda'))
+  flat = stream.linearize(j)
+  assert flat.dim == 1 and flat.iterate == 2
+  assert str(flat.output_stmts[0]) == (
+      'output dram 1 float: t0(0) = (t1(32) + t1(1) + t1(0) + t1(-32) + '
+      't1(-1)) * 0.2f')
+  h = stream.linearize(core.from_file(soda_path('heat3d.soda')))
+  assert 'in(1024)' in str(h.output_stmts[0]) and 'in(-32)' in str(
+      h.output_stmts[0])
+
+
+@pytest.mark.parametrize('name,extent', [('blur.soda', (2000, 12)),
+                                         ('jacobi2d.soda', (32, 12)),
+                                         ('jacobi2d.soda', (20, 9)),
+                                         ('heat3d.soda', (32, 32, 9)),
+                                         ('sobel2d.soda', (32, 8))])
+def test_wire_chain_with_cpu_kernel(name, extent):
+  from oracle import frt_layout, numpy_oracle
+  st = core.from_file(soda_path(name))
+  lay = stream.WireLayout(st, extent)
+  rng = np.random.default_rng(5)
+  ins = {}
+  for n, t in zip(st.input_names, st.input_types):
+    shape = tuple(extent[::-1])
+    ins[n] = (rng.random(shape).astype(t.np_name) if t.is_float else
+              rng.integers(-100, 100, shape).astype(t.np_name))
+  banks = frt_layout.scatter(lay, ins)
+  n = lay.cycle_count * lay.epc[st.input_names[0]]
+  streams = {}
+  for nme in st.input_names:
+    nb = lay.bank_count[nme]
+    s = np.zeros(n, banks[nme][0].dtype)
+    for b in range(nb):
+      s[b::nb] = banks[nme][b][:len(s[b::nb])]
+    streams[nme] = s
+  out1d = numpy_oracle.run(stream.linearize(st), streams)
+  out_banks = frt_layout.alloc(lay, st.output_names)
+  for o in st.output_names:
+    off, nb = lay.stencil_offset[o], lay.bank_count[o]
+    wire = np.zeros(n, out1d[o].dtype)
+    wire[off:] = out1d[o][:n - off]
+    for b in range(nb):
+      out_banks[o][b][:len(wire[b::nb])] = wire[b::nb]
+  got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(st.output_names, st.output_types)}
+  frt_layout.gather(lay, out_banks, got)
+  want = numpy_oracle.run(st, ins)
+  for o in st.output_names:
+    assert np.array_equal(got[o], want[o])
