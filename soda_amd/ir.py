@@ -458,6 +458,8 @@ def c_expr(node: Node,
   """C text of `node`.  `load(ref)` spells a tensor element, `var(v)` a let
   variable or param element.  Sub-expressions are always parenthesised, so C
   precedence can never regroup what the DSL grouped."""
+  if isinstance(node, _Text):
+    return node.text()
   if isinstance(node, Num):
     return node.c_literal
   if isinstance(node, Ref):
@@ -506,6 +508,76 @@ def c_expr(node: Node,
   if isinstance(node, Let):
     raise util.InternalError('render lets through their .expr')
   raise util.InternalError('cannot render %r' % (node,))
+
+
+def c_statements(node: Node, loads: Sequence[Callable[[Ref], str]],
+                 fresh: Callable[[], str],
+                 var: Callable[[Var], str] = lambda v: v.text()
+                 ) -> Tuple[List[str], List[str]]:
+  """`node` evaluated for several cells at once, as three-address C++
+  statements emitted OPERATION-major, cell-minor: every binary operation of
+  the tree becomes one `const auto t = a op b;` per cell, and the statements of
+  the different cells are interleaved.  Same operations in the same order per
+  cell as `c_expr` (so the same bits); what changes is that consecutive
+  statements are independent, which is the order the GPU's in-order waves want
+  (a wave issues back-to-back only if the next instruction does not depend on
+  the previous one).  Returns (statements, one result expression per cell).
+  `loads[c]` spells a tensor element for cell c."""
+  n = len(loads)
+  stmts: List[str] = []
+
+  def leaf(texts):
+    return texts
+
+  def ev(nd) -> List[str]:
+    if isinstance(nd, Num):
+      return [nd.c_literal] * n
+    if isinstance(nd, Ref):
+      return [loads[c](nd) for c in range(n)]
+    if isinstance(nd, Var):
+      return [var(nd)] * n
+    if isinstance(nd, Cast):
+      inner = ev(nd.expr)
+      return ['((%s)(%s))' % (nd.haoda_type.c_type, x) for x in inner]
+    if isinstance(nd, Unary):
+      inner = ev(nd.operand)
+      for op in reversed(nd.ops):
+        inner = ['(%s%s)' % (op, x) for x in inner]
+      return inner
+    if isinstance(nd, Chain):
+      acc = ev(nd.operands[0])
+      for op, operand in zip(nd.operators, nd.operands[1:]):
+        rhs = ev(operand)
+        names = []
+        for c in range(n):
+          t = fresh()
+          stmts.append('const auto %s = %s %s %s;' % (t, acc[c], op, rhs[c]))
+          names.append(t)
+        acc = names
+      return acc
+    # calls: fall back to the nested text per cell (arguments evaluated first)
+    if isinstance(nd, Call):
+      args = [ev(a) for a in nd.args]
+      out = []
+      for c in range(n):
+        sub = Call(nd.name, [_Text(args[k][c], nd.args[k].haoda_type)
+                             for k in range(len(nd.args))])
+        out.append(c_expr(sub, loads[c], var))
+      return out
+    raise util.InternalError('cannot render %r' % (nd,))
+
+  return stmts, ev(node)
+
+
+class _Text(Node):
+  """Already-rendered C text standing in for a sub-expression."""
+
+  def __init__(self, text: str, haoda_type: Optional[Type]):
+    self._text = text
+    self.haoda_type = haoda_type
+
+  def text(self) -> str:
+    return self._text
 
 
 C_PRELUDE = '''\
