@@ -154,6 +154,47 @@ template <class T> SODA_DEV T soda_lane_up(T v) { return soda_lane_shift<T>::up(
 template <class T> SODA_DEV T soda_lane_dn_or(T v, T edge) { return soda_lane_shift<T>::dn_or(v, edge); }
 template <class T> SODA_DEV T soda_lane_up_or(T v, T edge) { return soda_lane_shift<T>::up_or(v, edge); }
 
+// ---- lane shifts through the LDS crossbar (ds_bpermute_b32) -----------------
+// Measured on gfx950 (tools/valubench.py): a VALU op carrying a DPP shift
+// costs ~15 issue cycles against 2 for a plain one, whatever the DPP pattern;
+// ds_bpermute runs in the LDS pipe beside the VALU and, issued a stage ahead of
+// its use, costs only its issue slot.  Lane 0 (63) receives lane 63's (0's)
+// value instead of 0: only halo lanes see the difference.
+template <class T, int kSize = sizeof(T)>
+struct soda_bperm;
+template <class T>
+struct soda_bperm<T, 4> {
+  SODA_DEV T get(int byte_addr, T v) {
+    return __builtin_bit_cast(
+        T, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+  }
+};
+template <class T>
+struct soda_bperm<T, 8> {
+  struct pair { int lo, hi; };
+  SODA_DEV T get(int byte_addr, T v) {
+    pair p = __builtin_bit_cast(pair, v);
+    p.lo = __builtin_amdgcn_ds_bpermute(byte_addr, p.lo);
+    p.hi = __builtin_amdgcn_ds_bpermute(byte_addr, p.hi);
+    return __builtin_bit_cast(T, p);
+  }
+};
+template <class T>
+struct soda_bperm<T, 2> {
+  SODA_DEV T get(int byte_addr, T v) {
+    return (T)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
+  }
+};
+template <class T>
+struct soda_bperm<T, 1> {
+  SODA_DEV T get(int byte_addr, T v) {
+    return (T)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
+  }
+};
+template <class T> SODA_DEV T soda_lane_from(int byte_addr, T v) {
+  return soda_bperm<T>::get(byte_addr, v);
+}
+
 // ---- row fragments: V consecutive cells of one row per lane ----------------
 template <class T, int V>
 struct soda_vec {

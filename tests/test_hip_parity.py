@@ -192,7 +192,8 @@ def test_explicit_chunk_and_wave_shapes(built):
              dict(chunk_rows=300, prefetch=1),
              dict(chunk_rows=16, prefetch=4, nt_store=True, nt_load=False,
                   xcd_swizzle=False, edge_loads=False),
-             dict(warm_guards=True), dict(interleave=True), dict(vec=2),
+             dict(warm_guards=True), dict(interleave=True),
+             dict(lane_shift='bperm'), dict(vec=2),
              dict(vec=1, chunk_rows=33)):
     _check(stencil, (1000, 200), lower.LowerOptions(fuse=(3,), **kw))
   h = core.from_file(soda_path('heat3d.soda'), iterate=2)
