@@ -115,6 +115,10 @@ def cpu_baseline(stencil, extent, target_seconds):
 
 def main():
   args = parse_args()
+  # the C-ABI library is a build artefact (git-ignored): make sure it exists;
+  # a no-op when it is newer than its sources
+  import __graft_entry__ as entry
+  entry.build_library()
   import torch
   from soda_amd import core, dist as sdist, runtime
   from soda_amd.codegen.hip import lower
