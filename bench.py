@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=5)
-  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--soda', default=os.path.join(
       ROOT, 'tests', 'golden', 'soda', 'jacobi2d.soda'))
   ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])

@@ -69,7 +69,7 @@ def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
                             vec=args.hip_vec,
                             chunk_rows=args.hip_chunk_rows,
                             prefetch=args.hip_prefetch, waves_x=wx, waves_y=wy,
-                            nt_store=args.hip_nt_store,
+                            nt_store=True if args.hip_nt_store else None,
                             nt_load=False if args.hip_no_nt_load else None,
                             tile_rows=args.hip_tile_rows,
                             xcd_swizzle=not args.hip_no_xcd_swizzle)

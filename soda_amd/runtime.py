@@ -347,6 +347,10 @@ def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
     if best is None or cost < best[0] or (cost == best[0] and chunk > best[1]):
       best = (cost, chunk)
   chunk = best[1]
+  if warm <= 12:
+    # latency-bound kernels (few fused iterations): more, shorter waves beat
+    # the model's pick (blur 16384^2: 32-64 rows 232 us, 132 rows 245-294 us)
+    chunk = min(chunk, 64)
   chunks = -(-n // chunk)
   return max(1, -(-n // chunks))          # same count, equal lengths
 

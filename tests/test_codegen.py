@@ -225,7 +225,9 @@ def test_backend_plugin_surface():
   assert args.hip_kernel == '-' and args.hip_fuse == [2, 6]
   assert not args.hip_backend
   opts = hip.options_from_args(args)
-  assert opts.fuse == (2, 6) and opts.nt_load is None and not opts.nt_store
+  assert opts.fuse == (2, 6) and opts.nt_load is None and opts.nt_store is None
   assert opts.resolved(2).nt_load and not opts.resolved(3).nt_load
+  one_shot = opts.resolved(2, iterated=False)
+  assert one_shot.nt_store and not one_shot.nt_load
   stencil = core.from_file(soda_path('jacobi2d.soda'))
   assert hip.default_extent(stencil) == [32, 6]   # frt/host.py:454-461
