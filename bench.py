@@ -313,6 +313,18 @@ def main():
       if kname in measured:
         roofline['traffic'] = measured[kname]['hbm_bytes_per_launch']
         roofline['traffic_source'] = measured[kname].get('source')
+        insts = measured[kname].get('valu_wave_instructions_per_launch')
+        if insts:
+          # second roof of a temporally blocked stencil: VALU issue.  A wave64
+          # VALU op holds a SIMD for 2 cycles at best (tools/valubench.py);
+          # 1024 SIMDs at the 2.4 GHz peak clock.
+          issue_s = insts * 2.0 / (1024 * 2.4e9)
+          roofline['valu'] = {
+              'wave_instructions_per_launch': insts,
+              'min_issue_ms': issue_s * 1e3,
+              'frac_of_valu_issue_peak': issue_s * 1e3 / kernel_ms,
+              'source': 'rocprofv3 --pmc SQ_INSTS_VALU (profiles/traffic.json)',
+          }
     except (OSError, ValueError, KeyError):
       pass
 

@@ -43,6 +43,7 @@ def main():
   stats = read_stats(trace_dir)
   fetch = read_counters(fetch_dir)
   write = read_counters(write_dir)
+  valu = read_counters(sys.argv[5]) if len(sys.argv) > 5 else {}
   result = {}
   for name, st in stats.items():
     if 'march' not in name and 'direct' not in name and 'copy' not in name:
@@ -57,6 +58,16 @@ def main():
                    hbm_bytes_per_launch=fb + wb,
                    source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
                    'passes; FETCH_SIZE x2 (gfx950), x1024 B')
+    v = valu.get(name, {})
+    if v.get('SQ_INSTS_VALU'):
+      entry['valu_wave_instructions_per_launch'] = (
+          sum(v['SQ_INSTS_VALU']) / len(v['SQ_INSTS_VALU']))
+    if v.get('SQ_WAVES'):
+      entry['waves_per_launch'] = sum(v['SQ_WAVES']) / len(v['SQ_WAVES'])
+    if v.get('GRBM_GUI_ACTIVE'):
+      # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+      entry['gui_active_cycles_per_xcd'] = (
+          sum(v['GRBM_GUI_ACTIVE']) / len(v['GRBM_GUI_ACTIVE']) / 8)
     result[name] = entry
   with open(out_json, 'w') as f:
     json.dump(result, f, indent=1, sort_keys=True)
