@@ -334,6 +334,12 @@ int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
     if (!inputs[i]) return fail(SODA_HIP_ERR_INVALID, "run_device: NULL input");
   for (int i = 0; i < plan.num_outputs; ++i)
     if (!outputs[i]) return fail(SODA_HIP_ERR_INVALID, "run_device: NULL output");
+  for (int o = 0; o < plan.num_outputs; ++o)
+    for (int i = 0; i < plan.num_inputs; ++i)
+      if (outputs[o] == inputs[i])
+        return fail(SODA_HIP_ERR_INVALID,
+                    "run_device: an output aliases an input (in-place runs are "
+                    "not supported: inputs are read while outputs are written)");
 
   // schedule: as many passes of the most-fused kind as fit, then the next...
   int32_t count[SODA_HIP_MAX_PASSES];

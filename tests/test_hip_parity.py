@@ -216,6 +216,32 @@ def test_iterated_multi_stage_and_3d(built, name, iterate, fuse):
   _check(stencil, extent, lower.LowerOptions(fuse=fuse), oracle='c')
 
 
+@pytest.mark.parametrize('name,extent,fuse', [
+    ('coupled2d.soda', (300, 90), (2,)),     # 2 inputs -> 2 outputs, iterate 3
+    ('coupled2d.soda', (300, 90), ()),
+    ('lets2d.soda', (260, 70), ()),          # let variables, double, sqrt, max
+    ('ints2d.soda', (520, 66), ()),          # uint8/int32/int64, select/abs/%/^/&
+])
+@pytest.mark.parametrize('strategy', ['auto', 'direct'])
+def test_language_surface(built, name, extent, fuse, strategy):
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name))
+  _check(stencil, extent, lower.LowerOptions(strategy=strategy, fuse=fuse),
+         oracle='c')
+
+
+def test_in_place_is_rejected(built):
+  from soda_amd import core, runtime, util
+  from soda_amd.codegen.hip import lower
+  import torch
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=2)
+  a = torch.rand((64, 256), device='cuda')
+  with runtime.Program(stencil, lower.LowerOptions(), extent=(256, 64)) as prog:
+    with pytest.raises(util.BackendError, match='alias'):
+      prog.run_device([a.data_ptr()], [a.data_ptr()], (256, 64))
+
+
 def test_sodac_hip_backend_runs(built):
   """`sodac file.soda --hip-backend`: parse, JIT, run on the GPU, JSON out."""
   import json
