@@ -64,6 +64,19 @@ def linearize(stencil: core.Stencil) -> core.Stencil:
       replication_factor=stencil.replication_factor)
 
 
+def stencil_offsets(stencil: core.Stencil) -> Dict[str, int]:
+  """Where an output cell sits in its stream relative to its own in-tile
+  linear index: the largest linear offset of the output's overall stencil
+  window (reference frt/host.py:401-408)."""
+  tile = stencil.tile_size
+  out = {}
+  for s in stencil.output_stmts:
+    pts = stencil.stencil_window_points(s.name)
+    out[s.name] = core.get_stencil_distance(pts, tile) - util.serialize(
+        core.get_stencil_window_offset(pts), tile)
+  return out
+
+
 class WireLayout:
   """Sizes and offsets of the banked streams, formula for formula as the
   reference host computes them (frt/host.py line numbers in comments)."""
@@ -109,14 +122,7 @@ class WireLayout:
           self.stencil_distance, self.epc[s.name]))                    # :157-162
     self.cycle_count = -(-(self.elem_count_per_tile * self.tiles +
                            self.stencil_distance) // self.epc[in0])    # :272-276
-    # where an output cell sits in its stream relative to its own in-tile
-    # linear index (:401-408)
-    self.stencil_offset = {}
-    for s in st.output_stmts:
-      pts = st.stencil_window_points(s.name)
-      dist = core.get_stencil_distance(pts, tile)
-      self.stencil_offset[s.name] = dist - util.serialize(
-          core.get_stencil_window_offset(pts), tile)
+    self.stencil_offset = stencil_offsets(st)                          # :401-408
 
 
 _WIRE_SRC = '''
@@ -142,11 +148,7 @@ class StreamProgram:
     table = stencil.symbol_table
     self.banks = {s.name: len(s.dram)
                   for s in stencil.input_stmts + stencil.output_stmts}
-    # output shift is a program constant
-    probe = WireLayout(stencil, tuple(t if t > 0 else 8
-                                      for t in stencil.tile_size[:-1]) + (
-                                          stencil.stencil_dim[-1] + 1,))
-    self.stencil_offset = dict(probe.stencil_offset)
+    self.stencil_offset = stencil_offsets(stencil)   # a program constant
     self._lib = runtime.library()
     self._kernel = runtime.Program(self.flat,
                                    lower.LowerOptions(strategy='direct'),
