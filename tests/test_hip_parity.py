@@ -231,6 +231,17 @@ def test_language_surface(built, name, extent, fuse, strategy):
          oracle='c')
 
 
+@pytest.mark.parametrize('name,iterate', [('jacobi2d.soda', 3),
+                                          ('seidel2d.soda', 2)])
+def test_lds_halo_tile_variant(built, name, iterate):
+  """The classic LDS-tile kernel (the measured alternative to march2d)."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  _check(stencil, (1000, 150), lower.LowerOptions(strategy='lds'), oracle='c')
+  _check(stencil, (260, 33), lower.LowerOptions(strategy='lds'))
+
+
 def test_in_place_is_rejected(built):
   from soda_amd import core, runtime, util
   from soda_amd.codegen.hip import lower
