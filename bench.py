@@ -159,12 +159,8 @@ def main():
     if fuse > 1:
       ex = max(fuse, ex // fuse * fuse)
   else:
-    lo_r, hi_r = stencil.radius
-    reach = max(1, -lo_r[-1] + hi_r[-1])
-    own = extent[-1] // geo_world
-    ex = max(1, min(args.iterate, own // (2 * reach)))
-    if fuse > 1 and ex < args.iterate:
-      ex = max(fuse, ex // fuse * fuse)
+    ex = sdist.auto_exchange_every(stencil, extent, geo_world, args.iterate,
+                                   multiple_of=fuse)
   slab = sdist.Slab(stencil, extent, geo_world, geo_rank, ex)
   if emulate > 1:
     if sdist.rounds(args.iterate, ex) > 1:

@@ -107,6 +107,12 @@ def test_slab_geometry():
   assert up[1][1] - up[1][0] == dn[2][1] - dn[2][0] == 24
   assert slabs[3].begin + up[1][0] == slabs[4].begin + dn[2][0]
   assert sdist.rounds(100, 24) == 5
+  assert sdist.auto_exchange_every(st, (8192, 8192), 8, 100, 12) == 100
+  assert sdist.auto_exchange_every(st, (8192, 8192), 1, 100) == 100
+  j1000 = core.from_file(soda_path('jacobi2d.soda'), iterate=1000)
+  assert sdist.auto_exchange_every(j1000, (8192, 8192), 8, 1000, 12) == 120
+  h = core.from_file(soda_path('heat3d.soda'), iterate=50)
+  assert sdist.auto_exchange_every(h, (512, 512, 512), 8, 50) == 8
   uneven = [sdist.Slab(st, (64, 10), 3, r, 1) for r in range(3)]
   assert [s.own_rows for s in uneven] == [4, 3, 3]
   from soda_amd import util
