@@ -259,7 +259,13 @@ class Stencil:
         tlo, thi = stage.tap_bounds(parent)
         plo, phi = boxes[parent]
         for d in range(self.dim):
-          l, h = tlo[d] + plo[d], thi[d] + phi[d]
+          # min(plo, 0) / max(phi, 0): the loaded element itself must lie in
+          # the grid too.  Identical to the reference's window whenever every
+          # tensor's window spans offset 0 (true for its whole corpus); where
+          # it does not (`p(0) = in(2)`, `t(0) = p(-3)`) the reference's
+          # self-check loop would read p[-2] out of bounds.
+          l = tlo[d] + min(plo[d], 0)
+          h = thi[d] + max(phi[d], 0)
           lo[d] = l if lo[d] is None else min(lo[d], l)
           hi[d] = h if hi[d] is None else max(hi[d], h)
       if lo[0] is None:  # a stage of constants only

@@ -83,11 +83,27 @@ SODA_DEV int soda_dpp_shl1_or(int v, int edge) {
   return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false);
 }
 
-template <class T, int kSize = sizeof(T)>
+// The DPP result of INTEGER and 64-bit shifts is passed through an empty asm
+// so that LLVM's DPP-combine pass cannot fold the shift into the consuming
+// instruction: on ROCm 7.x that folding produced wrong results for fused
+// integer stencils (v_add_u32_dpp / v_subrev_u32_dpp; found by tests/
+// test_fuzz.py, fixed by -amdgpu-dpp-combine=false) and illegal encodings for
+// double ("DP ALU dpp only support row_newbcast", also for an fp32 shift folded
+// into v_cvt_f64_f32).  Pure 32-bit-float programs keep the folding
+// (v_add_f32_dpp; the generator defines SODA_FOLD_F32_DPP for them): it is what
+// the hot jacobi/heat kernels rely on, and every such program of the suites is
+// bit-exact with it.
+SODA_DEV int soda_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+template <class T, int kSize = sizeof(T), bool kFloat = __is_floating_point(T)>
 struct soda_lane_shift;
 
+#ifdef SODA_FOLD_F32_DPP   // set by the generator for programs without 64-bit types
 template <class T>
-struct soda_lane_shift<T, 4> {
+struct soda_lane_shift<T, 4, true> {
   SODA_DEV T dn(T v) {
     return __builtin_bit_cast(T, soda_dpp_shr1(__builtin_bit_cast(int, v)));
   }
@@ -104,49 +120,85 @@ struct soda_lane_shift<T, 4> {
   }
 };
 
+#endif
+
 template <class T>
-struct soda_lane_shift<T, 8> {
+struct soda_lane_shift<T, 4, false> {
+  SODA_DEV T dn(T v) {
+    return __builtin_bit_cast(T, soda_opaque(soda_dpp_shr1(__builtin_bit_cast(int, v))));
+  }
+  SODA_DEV T up(T v) {
+    return __builtin_bit_cast(T, soda_opaque(soda_dpp_shl1(__builtin_bit_cast(int, v))));
+  }
+  SODA_DEV T dn_or(T v, T edge) {
+    return __builtin_bit_cast(T, soda_opaque(soda_dpp_shr1_or(
+        __builtin_bit_cast(int, v), __builtin_bit_cast(int, edge))));
+  }
+  SODA_DEV T up_or(T v, T edge) {
+    return __builtin_bit_cast(T, soda_opaque(soda_dpp_shl1_or(
+        __builtin_bit_cast(int, v), __builtin_bit_cast(int, edge))));
+  }
+};
+
+#ifndef SODA_FOLD_F32_DPP
+// mixed-precision programs: an fp32 shift folded into v_cvt_f64_f32 is illegal
+template <class T>
+struct soda_lane_shift<T, 4, true> : soda_lane_shift<int, 4, false> {
+  typedef soda_lane_shift<int, 4, false> I;
+  SODA_DEV T dn(T v) { return __builtin_bit_cast(T, I::dn(__builtin_bit_cast(int, v))); }
+  SODA_DEV T up(T v) { return __builtin_bit_cast(T, I::up(__builtin_bit_cast(int, v))); }
+  SODA_DEV T dn_or(T v, T e) {
+    return __builtin_bit_cast(T, I::dn_or(__builtin_bit_cast(int, v), __builtin_bit_cast(int, e)));
+  }
+  SODA_DEV T up_or(T v, T e) {
+    return __builtin_bit_cast(T, I::up_or(__builtin_bit_cast(int, v), __builtin_bit_cast(int, e)));
+  }
+};
+#endif
+
+template <class T, bool kFloat>
+struct soda_lane_shift<T, 8, kFloat> {
   struct pair { int lo, hi; };
   SODA_DEV T dn(T v) {
     pair p = __builtin_bit_cast(pair, v);
-    p.lo = soda_dpp_shr1(p.lo);
-    p.hi = soda_dpp_shr1(p.hi);
+    p.lo = soda_opaque(soda_dpp_shr1(p.lo));
+    p.hi = soda_opaque(soda_dpp_shr1(p.hi));
     return __builtin_bit_cast(T, p);
   }
   SODA_DEV T up(T v) {
     pair p = __builtin_bit_cast(pair, v);
-    p.lo = soda_dpp_shl1(p.lo);
-    p.hi = soda_dpp_shl1(p.hi);
+    p.lo = soda_opaque(soda_dpp_shl1(p.lo));
+    p.hi = soda_opaque(soda_dpp_shl1(p.hi));
     return __builtin_bit_cast(T, p);
   }
   SODA_DEV T dn_or(T v, T edge) {
     pair p = __builtin_bit_cast(pair, v), q = __builtin_bit_cast(pair, edge);
-    p.lo = soda_dpp_shr1_or(p.lo, q.lo);
-    p.hi = soda_dpp_shr1_or(p.hi, q.hi);
+    p.lo = soda_opaque(soda_dpp_shr1_or(p.lo, q.lo));
+    p.hi = soda_opaque(soda_dpp_shr1_or(p.hi, q.hi));
     return __builtin_bit_cast(T, p);
   }
   SODA_DEV T up_or(T v, T edge) {
     pair p = __builtin_bit_cast(pair, v), q = __builtin_bit_cast(pair, edge);
-    p.lo = soda_dpp_shl1_or(p.lo, q.lo);
-    p.hi = soda_dpp_shl1_or(p.hi, q.hi);
+    p.lo = soda_opaque(soda_dpp_shl1_or(p.lo, q.lo));
+    p.hi = soda_opaque(soda_dpp_shl1_or(p.hi, q.hi));
     return __builtin_bit_cast(T, p);
   }
 };
 
-template <class T>
-struct soda_lane_shift<T, 2> {  // widened: one VGPR per element
-  SODA_DEV T dn(T v) { return (T)soda_dpp_shr1((int)v); }
-  SODA_DEV T up(T v) { return (T)soda_dpp_shl1((int)v); }
-  SODA_DEV T dn_or(T v, T edge) { return (T)soda_dpp_shr1_or((int)v, (int)edge); }
-  SODA_DEV T up_or(T v, T edge) { return (T)soda_dpp_shl1_or((int)v, (int)edge); }
+template <class T, bool kFloat>
+struct soda_lane_shift<T, 2, kFloat> {  // widened: one VGPR per element
+  SODA_DEV T dn(T v) { return (T)soda_opaque(soda_dpp_shr1((int)v)); }
+  SODA_DEV T up(T v) { return (T)soda_opaque(soda_dpp_shl1((int)v)); }
+  SODA_DEV T dn_or(T v, T edge) { return (T)soda_opaque(soda_dpp_shr1_or((int)v, (int)edge)); }
+  SODA_DEV T up_or(T v, T edge) { return (T)soda_opaque(soda_dpp_shl1_or((int)v, (int)edge)); }
 };
 
-template <class T>
-struct soda_lane_shift<T, 1> {
-  SODA_DEV T dn(T v) { return (T)soda_dpp_shr1((int)v); }
-  SODA_DEV T up(T v) { return (T)soda_dpp_shl1((int)v); }
-  SODA_DEV T dn_or(T v, T edge) { return (T)soda_dpp_shr1_or((int)v, (int)edge); }
-  SODA_DEV T up_or(T v, T edge) { return (T)soda_dpp_shl1_or((int)v, (int)edge); }
+template <class T, bool kFloat>
+struct soda_lane_shift<T, 1, kFloat> {
+  SODA_DEV T dn(T v) { return (T)soda_opaque(soda_dpp_shr1((int)v)); }
+  SODA_DEV T up(T v) { return (T)soda_opaque(soda_dpp_shl1((int)v)); }
+  SODA_DEV T dn_or(T v, T edge) { return (T)soda_opaque(soda_dpp_shr1_or((int)v, (int)edge)); }
+  SODA_DEV T up_or(T v, T edge) { return (T)soda_opaque(soda_dpp_shl1_or((int)v, (int)edge)); }
 };
 
 template <class T> SODA_DEV T soda_lane_dn(T v) { return soda_lane_shift<T>::dn(v); }

@@ -162,4 +162,8 @@ def test_stage_order_follows_dependences_not_file_order():
                      'local float: first(0, 0) = a(1, 0)\n'
                      'output float: o(0, 0) = second(0, 0)')
   assert [st.name for st in s.ordered_stages] == ['first', 'second', 'o']
-  assert s.window_bounds()['o'] == ((1, 1), (1, 1))
+  # the enumerated window is the single point (1, 1) ...
+  assert s.stencil_window_points('o') == ((1, 1),)
+  # ... but the box also keeps every LOADED element in the grid (the element
+  # second(0,0) reads, first(0,1), exists only where 0 is in range too)
+  assert s.window_bounds()['o'] == ((0, 0), (1, 1))
