@@ -93,6 +93,89 @@ def test_slabs_match_single_process(tmp_path, name, extent, iterate, every,
   assert np.array_equal(got[idx], want[idx])
 
 
+def _fuzz_worker(rank, world, port, seed, every, out_dir):
+  import sys
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import torch
+  import torch.distributed as tdist
+  import fuzz
+  from soda_amd import core, dist as sdist
+  from oracle import numpy_oracle
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  tdist.init_process_group('gloo', rank=rank, world_size=world)
+  text, dim, iterate = fuzz.program(seed)
+  stencil = core.from_text(text)
+  extent = list(fuzz.extent_for(seed, dim))
+  extent[-1] = max(extent[-1], 48)
+  slab = sdist.Slab(stencil, extent, world, rank, every)
+  full = fuzz.inputs_for(stencil, extent, seed)
+  src = [torch.from_numpy(full[n][slab.begin:slab.end].copy())
+         for n in stencil.input_names]
+  work_a = [torch.empty_like(t) for t in src]
+  work_b = [torch.empty_like(t) for t in src]
+
+  def step(dst, cur, lext, iters):
+    ins = {n: s.numpy() for n, s in zip(stencil.input_names, cur)}
+    outs = numpy_oracle.run(stencil, ins, iterate=iters)
+    for d, o in zip(dst, stencil.output_names):
+      d.copy_(torch.from_numpy(outs[o]))
+
+  res = sdist.run(slab, src, work_a, work_b, step, stencil.iterate, tdist)
+  for i, r in enumerate(res):
+    own = r[slab.ghost_lo:slab.ghost_lo + slab.own_rows].numpy()
+    np.save(os.path.join(out_dir, 'rank%d_out%d.npy' % (rank, i)), own)
+  tdist.barrier()
+  tdist.destroy_process_group()
+
+
+def _iterable_fuzz_seeds(count):
+  import fuzz
+  from soda_amd import core
+  out = []
+  seed = 0
+  while len(out) < count:
+    text, dim, iterate = fuzz.program(seed)
+    if iterate >= 2 and dim >= 2:
+      try:
+        core.from_text(text)
+        out.append(seed)
+      except Exception:
+        pass
+    seed += 1
+  return out
+
+
+@pytest.mark.parametrize('seed', _iterable_fuzz_seeds(5))
+def test_random_programs_on_two_slabs(tmp_path, seed):
+  """Random iterated multi-stage / multi-input programs (asymmetric reach,
+  non-zero store indices) cut into 2 slabs with an exchange every iteration."""
+  import torch.multiprocessing as mp
+  import fuzz
+  from soda_amd import core
+  from oracle import numpy_oracle
+  world = 2
+  port = _free_port()
+  mp.spawn(_fuzz_worker, args=(world, port, seed, 1, str(tmp_path)),
+           nprocs=world, join=True)
+  text, dim, iterate = fuzz.program(seed)
+  stencil = core.from_text(text)
+  extent = list(fuzz.extent_for(seed, dim))
+  extent[-1] = max(extent[-1], 48)
+  full = fuzz.inputs_for(stencil, extent, seed)
+  want = numpy_oracle.run(stencil, full)
+  for i, o in enumerate(stencil.output_names):
+    got = np.concatenate([
+        np.load(os.path.join(str(tmp_path), 'rank%d_out%d.npy' % (r, i)))
+        for r in range(world)], axis=0)
+    lo, hi = stencil.valid_box(extent, o)
+    if not all(h > l for l, h in zip(lo, hi)):
+      continue
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(got[idx], want[o][idx], equal_nan=True), text
+
+
 def test_slab_geometry():
   from soda_amd import core, dist as sdist
   st = core.from_file(soda_path('jacobi2d.soda'), iterate=100)
