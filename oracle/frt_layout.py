@@ -7,9 +7,11 @@ tiled, burst-aligned, bank-interleaved streams (:181-249) and gather of each
 output's valid region (:340-427).  It lets tests drive
 soda_amd.stream.StreamProgram exactly the way the unmodified reference host
 would.  Only single-input programs are covered (`produce_offset` of further
-inputs comes out of the reference's ILP), and tests use one tile per dimension:
-for several tiles the reference scatters with stride `tile - kStencilDim`
-(:225-227) but gathers with `tile - kStencilDim + 1` (:389-391)."""
+inputs comes out of the reference's ILP).  For several tiles the reference
+scatters with stride `tile - kStencilDim` (:225-227) but gathers with
+`tile - kStencilDim + 1` (:389-391), so what the caller gets back is not the
+n-D stencil of its array; multi-tile tests therefore compare against
+`kernel_on_streams` (the kernel's own contract) instead of the n-D oracle."""
 import itertools
 
 import numpy as np
@@ -115,3 +117,29 @@ def gather(layout, out_banks, outputs):
         vals[sel] = out_banks[name][b][tiled[sel] // nb]
       outputs[name][tuple(orig[::-1])] = vals
   return outputs
+
+
+def kernel_on_streams(layout, in_banks):
+  """What `<app>_kernel` must leave in the output banks: the causal 1-D form of
+  the program over the de-interleaved streams, each output delayed by its
+  stencil offset (host.py:401-408 reads it back from there).  Returns banks."""
+  from oracle import numpy_oracle
+  from soda_amd import stream
+  st = layout.stencil
+  n = layout.cycle_count * layout.epc[st.input_names[0]]
+  streams = {}
+  for name in st.input_names:
+    nb = layout.bank_count[name]
+    s = np.zeros(n, in_banks[name][0].dtype)
+    for b in range(nb):
+      s[b::nb] = in_banks[name][b][:len(s[b::nb])]
+    streams[name] = s
+  out1d = numpy_oracle.run(stream.linearize(st), streams)
+  out_banks = alloc(layout, st.output_names)
+  for o in st.output_names:
+    off, nb = layout.stencil_offset[o], layout.bank_count[o]
+    wire = np.zeros(n, out1d[o].dtype)
+    wire[off:] = out1d[o][:n - off]
+    for b in range(nb):
+      out_banks[o][b][:len(wire[b::nb])] = wire[b::nb]
+  return out_banks

@@ -139,7 +139,15 @@ extern "C" __global__ void __launch_bounds__(256) %(name)s(soda_hip_kargs_t a) {
 class StreamProgram:
   """`<app>_kernel` for one program: banked wire streams in, banked out."""
 
-  def __init__(self, stencil: core.Stencil, device: int = 0):
+  # narrower tiles leave most of a 64-lane x V-wide marching strip idle and the
+  # one-cell-per-thread linear form wins (heat3d 32x32 tiles: 0.67 vs 1.09 ms)
+  DENSE_MIN_TILE0 = 256
+
+  def __init__(self, stencil: core.Stencil, device: int = 0,
+               dense: Optional[bool] = None):
+    """`dense`: None = use the n-D marching kernels when the stream allows it
+    and the tile is wide enough to fill them, True = whenever the stream
+    allows it, False = always the linear form."""
     if stencil.param_stmts:
       raise util.SemanticError('stream mode does not support param tensors')
     self.stencil = stencil
@@ -150,9 +158,19 @@ class StreamProgram:
                   for s in stencil.input_stmts + stencil.output_stmts}
     self.stencil_offset = stencil_offsets(stencil)   # a program constant
     self._lib = runtime.library()
+    # two ways of running the program on the de-interleaved stream:
+    #  * as the ORIGINAL n-D program on the stream viewed as a dense array of
+    #    extent (tile_size..., rows) -- tiles are whole rows laid end to end --
+    #    with the fast marching kernels (built on first use);
+    #  * as the linearised 1-D program (always valid, one cell per thread).
     self._kernel = runtime.Program(self.flat,
                                    lower.LowerOptions(strategy='direct'),
                                    device=device)
+    self._dense = None
+    if dense is None:
+      dense = stencil.dim >= 2 and stencil.tile_size[0] >= self.DENSE_MIN_TILE0
+    self._dense_failed = not dense
+    self.last_mode = None
     # wire <-> dense copy kernels, one per tensor
     chunks = [lower.runtime_text()]
     self._copy = {}
@@ -244,16 +262,57 @@ class StreamProgram:
     for name in st.input_names:
       if len(in_banks[name]) != self.banks[name]:
         raise util.InputError('%s has %d banks' % (name, self.banks[name]))
+      if self.banks[name] == 1:
+        # one bank: the bank IS the dense stream, and inputs are never written
+        dense_in.append(in_banks[name][0])
+        continue
       d = self._dev(('in', name), n * table[name].size_in_bytes)
       self._launch(name, [d], in_banks[name], n, stream)
       dense_in.append(d)
     for name in st.output_names:
       dense_out.append(self._dev(('out', name), n * table[name].size_in_bytes))
-    self._kernel.run_device(dense_out, dense_in, (n,), st.iterate, stream)
+    if self._run_dense(dense_out, dense_in, n, epc[st.input_names[0]], stream):
+      self.last_mode = 'dense'
+    else:
+      self._kernel.run_device(dense_out, dense_in, (n,), st.iterate, stream)
+      self.last_mode = 'linear'
     for name, d in zip(st.output_names, dense_out):
       if len(out_banks[name]) != self.banks[name]:
         raise util.InputError('%s has %d banks' % (name, self.banks[name]))
       self._launch(name, out_banks[name], [d], n, stream)
+
+  def _run_dense(self, dense_out, dense_in, n: int, epc: int,
+                 stream: int) -> bool:
+    """Runs the original program on the stream seen as (tile..., rows).  Valid
+    when the stream really is such an array:
+      * every tile starts on a row-block boundary.  A tile occupies
+        round_up(block * extent_last, epc) elements (frt/host.py:137-142), so
+        this holds for any extent iff block % epc == 0 (the kernel is not told
+        the extent, only the cycle count);
+      * the void tail the host appends (kStencilDistance elements,
+        frt/host.py:151-162) is at least one row block, so that the partial
+        last row the view drops holds no cell of any tile.
+    Cells whose taps cross a tile edge read zeros here and wrapped neighbours
+    in the linear form: both are outside the valid region."""
+    st = self.stencil
+    if st.dim < 2 or self._dense_failed:
+      return False
+    block = 1
+    for t in st.tile_size[:-1]:
+      block *= t
+    rows = n // block
+    if rows < 1 or st.stencil_distance < block or block % epc:
+      return False
+    extent = tuple(st.tile_size[:-1]) + (rows,)
+    if self._dense is None:
+      try:
+        self._dense = runtime.Program(st, lower.LowerOptions(),
+                                      device=self.device, extent=extent)
+      except util.SodaError:
+        self._dense_failed = True
+        return False
+    self._dense.run_device(dense_out, dense_in, extent, st.iterate, stream)
+    return True
 
   # -- <app>_kernel on host banks (what SODA_CPP_BINDING links against) ------
   def run_banked_host(self, out_banks: Dict[str, list], in_banks: Dict[str, list],
@@ -290,6 +349,9 @@ class StreamProgram:
     if getattr(self, '_kernel', None):
       self._kernel.close()
       self._kernel = None
+    if getattr(self, '_dense', None):
+      self._dense.close()
+      self._dense = None
 
   def __del__(self):
     try:

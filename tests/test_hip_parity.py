@@ -374,19 +374,36 @@ def test_full_size_properties(built, name, extent, iterate, fuse):
       assert np.array_equal(got[o], unfused[o])
 
 
+# (file, input decl override, extent, output decl override, mode): `dense` =
+# the stream is run as the original n-D program with the marching kernels
+# (tile row block a multiple of the burst), `linear` = as the 1-D program,
+# `fallback` = dense requested but the tile is not burst-aligned
 STREAM_CASES = [
-    ('blur.soda', None, (2000, 20), None),
-    ('jacobi2d.soda', None, (32, 12), None),          # iterate 2, as shipped
-    ('jacobi2d.soda', None, (20, 9), None),           # narrower than the tile
-    ('heat3d.soda', None, (32, 32, 9), None),         # iterate 2, 3-D tiles
-    ('sobel2d.soda', None, (32, 8), None),            # three stages, int16
+    ('blur.soda', None, (2000, 20), None, 'dense'),
+    ('blur.soda', None, (2000, 20), None, 'linear'),
+    ('jacobi2d.soda', 'input dram 0 float: t1(33, *)', (33, 12), None,
+     'fallback'),                                     # 33 % (64 / 32) != 0
+    ('jacobi2d.soda', 'input dram 0 float: t1(33, *)', (80, 11), None,
+     'fallback'),                                     # ... and padded tiles
+    ('blur.soda', 'input dram 0 uint16: input(2048, *)', (2048, 20), None,
+     'dense'),
+    ('blur.soda', 'input dram 0 uint16: input(2048, *)', (5000, 37), None,
+     'dense'),                                        # three tiles, ragged last
+    ('jacobi2d.soda', None, (32, 12), None, 'dense'),  # iterate 2, as shipped
+    ('jacobi2d.soda', None, (32, 12), None, 'linear'),
+    ('jacobi2d.soda', None, (20, 9), None, 'dense'),   # narrower than the tile
+    ('jacobi2d.soda', None, (100, 9), None, 'dense'),  # four overlapping tiles
+    ('heat3d.soda', None, (32, 32, 9), None, 'dense'),  # iterate 2, 3-D tiles
+    ('heat3d.soda', None, (32, 32, 9), None, 'linear'),
+    ('heat3d.soda', None, (70, 40, 7), None, 'dense'),  # 3 x 2 tiles
+    ('sobel2d.soda', None, (32, 8), None, 'dense'),    # three stages, int16
     ('jacobi2d.soda', 'input dram 0.1 float: t1(32, *)', (32, 12),
-     'output dram 2.3 float:'),                       # two banks each side
+     'output dram 2.3 float:', 'dense'),              # two banks each side
 ]
 
 
-@pytest.mark.parametrize('name,in_decl,extent,out_decl', STREAM_CASES)
-def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl):
+@pytest.mark.parametrize('name,in_decl,extent,out_decl,mode', STREAM_CASES)
+def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
   """<app>_kernel(out banks, in banks, coalesced_data_num) on the
   reference's tiled / burst-aligned / bank-interleaved streams, driven by a
   restatement of the reference host's scatter and gather."""
@@ -395,21 +412,30 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl):
   from oracle import frt_layout, numpy_oracle
   text = open(soda_path(name)).read()
   if in_decl:
-    text = re.sub(r'input dram \d+ float: t1\(32, \*\)', in_decl, text)
+    text = re.sub(r'input dram [^\n]*', in_decl, text)
+  if out_decl:
     text = re.sub(r'output dram \d+ float:', out_decl, text)
   stencil = core.from_text(text)
   inputs = _inputs(stencil, extent, seed=5)
   layout = stream.WireLayout(stencil, extent)
   in_banks = frt_layout.scatter(layout, inputs)
   out_banks = frt_layout.alloc(layout, stencil.output_names)
-  prog = stream.StreamProgram(stencil)
+  prog = stream.StreamProgram(stencil, dense=mode != 'linear')
   try:
     prog.run_banked_host(out_banks, in_banks, layout.cycle_count)
+    assert prog.last_mode == ('dense' if mode == 'dense' else 'linear')
   finally:
     prog.close()
   got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
          for o, t in zip(stencil.output_names, stencil.output_types)}
   frt_layout.gather(layout, out_banks, got)
+  # the kernel's contract: every cell the host reads back (any tile count)
+  ref = {o: np.zeros_like(got[o]) for o in got}
+  frt_layout.gather(layout, frt_layout.kernel_on_streams(layout, in_banks), ref)
+  for o in stencil.output_names:
+    assert np.array_equal(got[o], ref[o]), o
+  if layout.tiles > 1:
+    return       # the reference host's own tile strides disagree (frt_layout)
   want = numpy_oracle.run(stencil, inputs)
   for o in stencil.output_names:
     assert np.array_equal(got[o], want[o]), o

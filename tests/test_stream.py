@@ -75,3 +75,62 @@ def test_wire_chain_with_cpu_kernel(name, extent):
   want = numpy_oracle.run(st, ins)
   for o in st.output_names:
     assert np.array_equal(got[o], want[o])
+
+
+@pytest.mark.parametrize('name,extent', [('blur.soda', (2000, 12)),
+                                         ('blur.soda', (4500, 9)),
+                                         ('jacobi2d.soda', (32, 12)),
+                                         ('jacobi2d.soda', (100, 9)),
+                                         ('heat3d.soda', (70, 40, 7)),
+                                         ('sobel2d.soda', (32, 8))])
+def test_wire_chain_as_dense_view(name, extent):
+  """The property StreamProgram's `dense` mode rests on: when a tile's row block
+  is a whole number of bursts, the stream IS a dense (tile..., rows) array and
+  the original n-D program run on that view yields the same valid cells as the
+  causal 1-D form."""
+  from oracle import frt_layout, numpy_oracle
+  st = core.from_file(soda_path(name))
+  lay = stream.WireLayout(st, extent)
+  rng = np.random.default_rng(6)
+  ins = {}
+  for n, t in zip(st.input_names, st.input_types):
+    shape = tuple(extent[::-1])
+    ins[n] = (rng.random(shape).astype(t.np_name) if t.is_float else
+              rng.integers(-100, 100, shape).astype(t.np_name))
+  banks = frt_layout.scatter(lay, ins)
+  n = lay.cycle_count * lay.epc[st.input_names[0]]
+  block = int(np.prod(st.tile_size[:-1]))
+  assert block % lay.epc[st.input_names[0]] == 0
+  assert st.stencil_distance >= block
+  rows = n // block
+  view = tuple(st.tile_size[:-1]) + (rows,)
+  dense_in = {}
+  for nme in st.input_names:
+    nb = lay.bank_count[nme]
+    s = np.zeros(n, banks[nme][0].dtype)
+    for b in range(nb):
+      s[b::nb] = banks[nme][b][:len(s[b::nb])]
+    dense_in[nme] = s[:rows * block].reshape(view[::-1])
+  out_nd = numpy_oracle.run(st, dense_in)
+  out_banks = frt_layout.alloc(lay, st.output_names)
+  for o in st.output_names:
+    off, nb = lay.stencil_offset[o], lay.bank_count[o]
+    flat = np.zeros(n, out_nd[o].dtype)
+    flat[:rows * block] = out_nd[o].reshape(-1)
+    wire = np.zeros(n, flat.dtype)
+    wire[off:] = flat[:n - off]
+    for b in range(nb):
+      out_banks[o][b][:len(wire[b::nb])] = wire[b::nb]
+  got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(st.output_names, st.output_types)}
+  frt_layout.gather(lay, out_banks, got)
+  # the kernel's own contract: every cell the host reads back equals the
+  # causal 1-D form's (several tiles included)
+  ref = {o: np.zeros_like(got[o]) for o in got}
+  frt_layout.gather(lay, frt_layout.kernel_on_streams(lay, banks), ref)
+  for o in st.output_names:
+    assert np.array_equal(got[o], ref[o])
+  if lay.tiles == 1:
+    want = numpy_oracle.run(st, ins)
+    for o in st.output_names:
+      assert np.array_equal(got[o], want[o])

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Times `<app>_kernel` on wire streams: unwire + program + wire,
+device-resident banks, `dense` (marching kernels on the (tile..., rows) view)
+against `linear` (causal 1-D form).  One JSON line per mode."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--soda', default='tests/golden/soda/blur.soda')
+  ap.add_argument('--extent', type=int, nargs='+', default=[2000, 16384])
+  ap.add_argument('--steps', type=int, default=10)
+  args = ap.parse_args()
+  from soda_amd import core, runtime, stream
+  st = core.from_file(args.soda)
+  lay = stream.WireLayout(st, args.extent)
+  lib = runtime.library()
+  table = st.symbol_table
+
+  def dev_banks(names):
+    out = {}
+    for n in names:
+      nb = lay.bank_count[n]
+      out[n] = []
+      for _ in range(nb):
+        p = ctypes.c_void_p()
+        nbytes = lay.buf_elems[n] // nb * table[n].size_in_bytes
+        runtime.check(lib.soda_hip_malloc(0, nbytes, ctypes.byref(p)), 'malloc')
+        runtime.check(lib.soda_hip_memset(p, 1, nbytes, None), 'memset')
+        out[n].append(p.value)
+    return out
+
+  ins, outs = dev_banks(st.input_names), dev_banks(st.output_names)
+  cells = 1
+  for e in args.extent:
+    cells *= e
+  for mode in ('dense', 'linear'):
+    prog = stream.StreamProgram(st, dense=mode == 'dense')
+    for _ in range(3):
+      prog.run_banked_device(outs, ins, lay.cycle_count)
+    runtime.synchronize()
+    e0, e1 = runtime.Event(), runtime.Event()
+    e0.record()
+    for _ in range(args.steps):
+      prog.run_banked_device(outs, ins, lay.cycle_count)
+    e1.record()
+    runtime.synchronize()
+    ms = e0.elapsed_ms(e1) / args.steps
+    print(json.dumps({'soda': os.path.basename(args.soda), 'extent': args.extent,
+                      'mode': prog.last_mode, 'ms_per_call': round(ms, 4),
+                      'cells_iters_per_s': cells * st.iterate / ms * 1e3,
+                      'tiles': lay.tiles}))
+    prog.close()
+
+
+if __name__ == '__main__':
+  main()
