@@ -288,3 +288,92 @@ SODA_DEV void soda_store_frag(T* __restrict__ p, const T (&src)[V]) {
       *reinterpret_cast<vec_t*>(p) = t;
   }
 }
+
+// ---- the same fragments through buffer resources ---------------------------
+// A raw buffer access whose offset is >= num_records is dropped by the memory
+// pipeline (loads return 0, stores vanish): rows above/below the grid, lanes
+// beyond the row end and pipeline warm-up need NO branch, so every vector-memory
+// instruction of the marching loop is straight-line code and the compiler's
+// s_waitcnt insertion can count them exactly.  (With `if (row_ok) load` the
+// counters merge pessimistically at each join and the loop got an
+// `s_waitcnt vmcnt(0)` right behind its prefetch loads.)
+//
+// Offsets are unsigned bytes from the start of the wave's window of a tensor;
+// the host keeps windows <= SODA_BUF_WINDOW_MAX bytes so that
+//   valid + valid < 2^30,  valid + SODA_OOB_X in [2^30, 2^31),
+//   SODA_OOB_ROW + anything >= 2^31 without wrapping.
+typedef unsigned soda_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned soda_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t soda_rsrc_t;
+#define SODA_OOB_X 0x40000000u
+#define SODA_OOB_ROW 0x80000000u
+#define SODA_BUF_WINDOW_MAX 0x40000000ll
+
+SODA_DEV soda_rsrc_t soda_make_rsrc(const void* base, int64_t bytes) {
+  // word 3 = 0x00020000: raw buffer, 32-bit data format (gfx9 encoding)
+  return __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(base), 0,
+      (int)(bytes < 0 ? 0 : bytes > SODA_BUF_WINDOW_MAX ? SODA_BUF_WINDOW_MAX
+                                                        : bytes),
+      0x00020000);
+}
+
+template <class T, int V, bool kNonTemporal = false>
+SODA_DEV void soda_buf_load_frag(T (&dst)[V], soda_rsrc_t r, unsigned off) {
+  constexpr int kBytes = V * (int)sizeof(T);
+  constexpr int kAux = kNonTemporal ? 2 : 0;   // gfx94x/95x: bit 1 = nt
+  if constexpr (kBytes % 16 == 0) {
+#pragma unroll
+    for (int i = 0; i < kBytes / 16; ++i) {
+      const soda_u32x4 t =
+          __builtin_amdgcn_raw_buffer_load_b128(r, off + 16 * i, 0, kAux);
+      __builtin_memcpy((char*)dst + 16 * i, &t, 16);
+    }
+  } else if constexpr (kBytes == 8) {
+    const soda_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, kAux);
+    __builtin_memcpy(dst, &t, 8);
+  } else if constexpr (kBytes == 4) {
+    const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, kAux);
+    __builtin_memcpy(dst, &t, 4);
+  } else if constexpr (kBytes == 2) {
+    const unsigned short t =
+        __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, kAux);
+    __builtin_memcpy(dst, &t, 2);
+  } else {
+    static_assert(kBytes == 1, "fragment size");
+    const unsigned char t = __builtin_amdgcn_raw_buffer_load_b8(r, off, 0, kAux);
+    __builtin_memcpy(dst, &t, 1);
+  }
+}
+
+template <class T, int V, bool kNonTemporal = false>
+SODA_DEV void soda_buf_store_frag(soda_rsrc_t r, unsigned off,
+                                  const T (&src)[V]) {
+  constexpr int kBytes = V * (int)sizeof(T);
+  constexpr int kAux = kNonTemporal ? 2 : 0;
+  if constexpr (kBytes % 16 == 0) {
+#pragma unroll
+    for (int i = 0; i < kBytes / 16; ++i) {
+      soda_u32x4 t;
+      __builtin_memcpy(&t, (const char*)src + 16 * i, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(t, r, off + 16 * i, 0, kAux);
+    }
+  } else if constexpr (kBytes == 8) {
+    soda_u32x2 t;
+    __builtin_memcpy(&t, src, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, kAux);
+  } else if constexpr (kBytes == 4) {
+    unsigned t;
+    __builtin_memcpy(&t, src, 4);
+    __builtin_amdgcn_raw_buffer_store_b32(t, r, off, 0, kAux);
+  } else if constexpr (kBytes == 2) {
+    unsigned short t;
+    __builtin_memcpy(&t, src, 2);
+    __builtin_amdgcn_raw_buffer_store_b16(t, r, off, 0, kAux);
+  } else {
+    static_assert(kBytes == 1, "fragment size");
+    unsigned char t;
+    __builtin_memcpy(&t, src, 1);
+    __builtin_amdgcn_raw_buffer_store_b8(t, r, off, 0, kAux);
+  }
+}

@@ -355,6 +355,22 @@ def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
   return max(1, -(-n // chunks))          # same count, equal lengths
 
 
+BUF_WINDOW_MAX = 1 << 30    # SODA_BUF_WINDOW_MAX in csrc/soda_rt.h
+
+
+def max_chunk_for_window(tune: dict, extent: Sequence[int]) -> Optional[int]:
+  """Longest chunk whose input window (chunk + stencil reach planes of the
+  widest tensor) still fits the buffer-offset encoding of csrc/soda_rt.h;
+  None for kernels that address memory through plain pointers."""
+  extra = tune.get('window_extra')
+  if extra is None:
+    return None
+  plane = tune.get('max_elem', 8)
+  for d in range(tune['axis']):
+    plane *= extent[d]
+  return BUF_WINDOW_MAX // plane - extra
+
+
 def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
   """Cells per lane per row: 16 bytes' worth, reduced until it divides the
   row length (rows must stay 16-byte aligned for the vector loads)."""
@@ -406,6 +422,14 @@ class Program:
       tile = list(k.tile)
       per_wave = tuned_chunk(k.tune, tile, k.block[0] * k.block[1] * k.block[2],
                              res['vgpr'], extent)
+      limit = max_chunk_for_window(k.tune, extent)
+      if limit is not None:
+        if limit < 1:
+          raise util.InputError(
+              '%s: one plane of extent %s exceeds the 1 GiB buffer window of '
+              'the marching kernels; use --hip-strategy direct' %
+              (k.name, tuple(extent)))
+        per_wave = min(per_wave, limit)
       tile[axis] = per_wave * k.tune['waves_along']
       k.tile = tuple(tile)
       self.plan.kernels[i].tile[axis] = tile[axis]
@@ -438,6 +462,17 @@ class Program:
       raise util.InputError(
           'this program was built for rows that are a multiple of %d cells; '
           'rebuild it for extent %s' % (self.opts.vec, tuple(extent)))
+    for k in self.module.kernels:
+      limit = max_chunk_for_window(k.tune, extent) if k.tune else None
+      if limit is not None:
+        axis = k.tune['axis']
+        per_wave = k.tile[axis] // max(1, k.tune['waves_along'])
+        if per_wave > limit:
+          raise util.InputError(
+              '%s: chunks of %d planes of extent %s exceed the 1 GiB buffer '
+              'window of the marching kernels; rebuild the program for this '
+              'extent (or use --hip-strategy direct)' %
+              (k.name, per_wave, tuple(extent)))
 
   # -- device-resident arrays (the <app>_kernel analogue) ------------------
   def run_device(self, outputs: Sequence[int], inputs: Sequence[int],

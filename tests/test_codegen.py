@@ -95,7 +95,8 @@ def test_march2d_geometry_for_jacobi2d():
   assert k1.tile[:2] == (256, 64)
   assert by_t[1].traffic_model['edge'] == (1, 1)
   assert by_t[4].traffic_model['edge'] == (0, 0)
-  assert by_t[4].traffic_model['warm_rows'] == 2 + 4 + 4
+  # T rows of reach below + T above; the prefetch-fill ticks are load-only
+  assert by_t[4].traffic_model["warm_rows"] == 4 + 4
   assert by_t[4].traffic_model['bytes_per_cell_min'] == 8
   src = mod.source
   assert 'soda_lane_dn' in src and 'soda_lane_up' in src
@@ -231,3 +232,37 @@ def test_backend_plugin_surface():
   assert one_shot.nt_store and not one_shot.nt_load
   stencil = core.from_file(soda_path('jacobi2d.soda'))
   assert hip.default_extent(stencil) == [32, 6]   # frt/host.py:454-461
+
+
+def test_buffer_window_limits_the_chunk():
+  """Marching kernels address a wave's window of a tensor with 32-bit buffer
+  offsets (csrc/soda_rt.h): the host caps the chunk so the window stays within
+  1 GiB, and refuses extents whose single plane does not fit."""
+  from soda_amd import runtime
+  tune = dict(axis=2, window_extra=2, max_elem=4)
+  # 4096 x 4096 floats = 64 MiB per plane -> 16 planes per GiB, 2 of them halo
+  assert runtime.max_chunk_for_window(tune, (4096, 4096, 100)) == 14
+  assert runtime.max_chunk_for_window(tune, (32768, 16384, 9)) < 1
+  assert runtime.max_chunk_for_window(dict(axis=1), (8192, 8192)) is None
+  tune2 = dict(axis=1, window_extra=26, max_elem=4)
+  assert runtime.max_chunk_for_window(tune2, (8192, 8192)) == 32768 - 26
+
+
+def test_march_loop_body_is_branch_free():
+  """The point of buffer addressing: no `if` around any load or store of the
+  marching loop, and a load-only prologue as deep as the prefetch."""
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  mod = lower.lower(stencil, lower.LowerOptions(fuse=()))
+  src = mod.source
+  loop = src[src.index('for (; tau < tau_end'):]
+  assert 'soda_buf_load_frag' in loop and 'soda_buf_store_frag' in loop
+  assert 'if (' not in loop
+  assert src.count('// prologue: loads of plane') == lower.default_prefetch(1)
+  # a stage without inputs forbids the peeling (its planes start at tick 0)
+  text = open(soda_path('jacobi2d.soda')).read()
+  const = core.from_text(
+      'kernel: c\nburst width: 64\nunroll factor: 2\niterate: 1\n'
+      'input float: a(32, *)\noutput float: b(0, 0) = a(0, 1) + a(0, -1)\n'
+      'output float: c(0, 0) = 38\n')
+  assert '// prologue' not in lower.lower(const, lower.LowerOptions(fuse=())).source
