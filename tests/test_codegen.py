@@ -60,6 +60,8 @@ def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
   stencil = core.from_file(soda_path(name))
   fuse = (3,) if (len(stencil.input_names) == len(stencil.output_names) and
                   stencil.input_types == stencil.output_types) else ()
+  if fuse:    # fused kernels are only built up to the program's iterate
+    stencil = core.from_file(soda_path(name), iterate=3)
   opts = lower.LowerOptions(fuse=fuse)
   opts.vec = runtime.pick_vec(stencil, None)
   mod = lower.lower(stencil, opts)
@@ -69,8 +71,8 @@ def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
   assert code[:4] == b'\x7fELF'
   for k in mod.kernels:
     assert k.name.encode() in code
-  direct_only = ('erosion.soda', 'xcorr.soda', 'contrast.soda',
-                 'denoise3d.soda')   # windows too tall / too many registers
+  # 17 x 17 taps: too many lane-shifted operands per row for register windows
+  direct_only = ('contrast.soda',)
   if name in direct_only:
     assert all(p.kind == 'direct' for p in mod.passes)
   elif stencil.dim == 2:
@@ -82,7 +84,7 @@ def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
 
 def test_march2d_geometry_for_jacobi2d():
   from soda_amd.codegen.hip import lower
-  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=4)
   opts = lower.LowerOptions(fuse=(4,), vec=4, chunk_rows=64)
   mod = lower.lower(stencil, opts)
   by_t = {p.fused_iters: p for p in mod.passes}
