@@ -103,7 +103,8 @@ def main():
     rows.append(dict(fuse=fuse, chunk=cfg[1], prefetch=cfg[2], waves=cfg[3],
                      nt_store=cfg[4], nt_load=cfg[5], xcd=cfg[6], vec=cfg[7], tile_rows=cfg[8], edge=cfg[9], wg=cfg[10], il=cfg[11], shift=cfg[12], mw=cfg[13], occ=cfg[14], buf=cfg[15], ms_min=best,
                      ms_med=med, GBs=cells * bytes_cell / best / 1e6,
-                     Gcell_iters=cells * fuse / best / 1e6))
+                     Gcell_iters=cells * fuse / best / 1e6,
+                     kernel=progs[i][0].module.kernels[0].name))
   rows.sort(key=lambda r: (r['fuse'], r['ms_min']))
   for r in rows:
     print(json.dumps(r))
