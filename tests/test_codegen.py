@@ -79,7 +79,8 @@ def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
     assert all(p.kind == 'march2d' for p in mod.passes)
     assert sorted(p.fused_iters for p in mod.passes) == sorted({1} | set(fuse))
   else:
-    assert [p.kind for p in mod.passes] == ['march3d']
+    assert all(p.kind == 'march3d' for p in mod.passes)
+    assert max(p.fused_iters for p in mod.passes) <= lower.MAX_FUSE_3D
 
 
 def test_march2d_geometry_for_jacobi2d():
@@ -109,7 +110,12 @@ def test_march3d_geometry_for_heat3d():
   from soda_amd.codegen.hip import lower
   stencil = core.from_file(soda_path('heat3d.soda'))
   mod = lower.lower(stencil, lower.LowerOptions(vec=4))
-  (p,) = mod.passes
+  by_t = {q.fused_iters: q for q in mod.passes}
+  # heat3d ships with iterate 2: the default fusion depth is capped at 2 in 3-D
+  assert sorted(by_t) == [1, lower.MAX_FUSE_3D]
+  p2 = by_t[2]
+  assert p2.kind == 'march3d' and p2.traffic_model['rows_in'] == 4 + 2 * 2
+  p = by_t[1]
   k = mod.kernels[p.kernels[0]]
   # 512-wide grids: two aligned 256-cell strips; 4 output rows + 2 halo rows
   # in registers; 64 planes marched per wave

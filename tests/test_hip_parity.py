@@ -205,6 +205,8 @@ def test_explicit_chunk_and_wave_shapes(built):
 @pytest.mark.parametrize('name,iterate,fuse', [
     ('blur.soda', 3, (2,)), ('blur.soda', 4, (4,)), ('seidel2d.soda', 7, (3,)),
     ('jacobi3d.soda', 3, ()), ('heat3d.soda', 5, ()),
+    ('jacobi3d.soda', 3, (2,)), ('heat3d.soda', 5, (2,)),   # 3-D, T=2 fused
+    ('heat3d.soda', 4, (4,)),                               # capped at T=2
 ])
 def test_iterated_multi_stage_and_3d(built, name, iterate, fuse):
   """Temporal blocking of a two-stage program (4 stages fused for blur x 2)

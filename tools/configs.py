@@ -75,8 +75,9 @@ def main():
   out.append(measure('jacobi2d.soda', (8192, 8192), 100, (), label='C2 jacobi2d 8192^2 it=100, one iteration per launch'))
   out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 4), label='C2 jacobi2d 8192^2 it=100, T=12 fused'))
   out.append(measure('blur.soda', (16384, 16384), 1, (), label='C3 blur 16384^2 fused two-stage', reps=20))
-  out.append(measure('heat3d.soda', (512, 512, 512), 50, (), label='C4 heat3d 512^3 it=50, 1 GPU'))
-  out.append(measure('heat3d.soda', (512, 512, 512), 50, (), world=8, label='C4 heat3d 512^3 it=50, slab of an 8-GPU run (compute only, exchanges not timed)'))
+  out.append(measure('heat3d.soda', (512, 512, 512), 50, (), label='C4 heat3d 512^3 it=50, one iteration per launch, 1 GPU'))
+  out.append(measure('heat3d.soda', (512, 512, 512), 50, (2,), label='C4 heat3d 512^3 it=50, T=2 fused, 1 GPU'))
+  out.append(measure('heat3d.soda', (512, 512, 512), 50, (2,), world=8, label='C4 heat3d 512^3 it=50, T=2, slab of an 8-GPU run (compute only, exchanges not timed)'))
   out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 4), label='C5 jacobi2d 8192^2 it=1000, T=12 fused, 1 GPU', reps=2))
   out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 4), world=8, label='C2 jacobi2d 8192^2 it=100, slab of an 8-GPU run (exchange-free)'))
   out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 4), world=8, label='C5 jacobi2d 8192^2 it=1000, slab of an 8-GPU run (compute only, exchanges not timed)', reps=2))
