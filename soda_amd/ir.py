@@ -512,7 +512,8 @@ def c_expr(node: Node,
 
 def c_statements(node: Node, loads: Sequence[Callable[[Ref], str]],
                  fresh: Callable[[], str],
-                 var: Callable[[Var], str] = lambda v: v.text()
+                 var: Callable[[Var], str] = lambda v: v.text(),
+                 stmts: Optional[List[str]] = None
                  ) -> Tuple[List[str], List[str]]:
   """`node` evaluated for several cells at once, as three-address C++
   statements emitted OPERATION-major, cell-minor: every binary operation of
@@ -522,9 +523,12 @@ def c_statements(node: Node, loads: Sequence[Callable[[Ref], str]],
   statements are independent, which is the order the GPU's in-order waves want
   (a wave issues back-to-back only if the next instruction does not depend on
   the previous one).  Returns (statements, one result expression per cell).
-  `loads[c]` spells a tensor element for cell c."""
+  `loads[c]` spells a tensor element for cell c.  A caller-supplied `stmts`
+  list is appended to, so a load callback may itself emit statements (e.g. the
+  fetch of the row it is about to name) right before their first use."""
   n = len(loads)
-  stmts: List[str] = []
+  if stmts is None:
+    stmts = []
 
   def leaf(texts):
     return texts

@@ -457,8 +457,7 @@ class Program:
   def _check_extent(self, extent: Sequence[int]) -> None:
     if len(extent) != self.stencil.dim:
       raise util.InputError('extent must have %d entries' % self.stencil.dim)
-    if self.opts.vec > 1 and extent[0] % self.opts.vec and any(
-        p.kind != 'direct' for p in self.module.passes):
+    if self.opts.vec > 1 and extent[0] % self.opts.vec:
       raise util.InputError(
           'this program was built for rows that are a multiple of %d cells; '
           'rebuild it for extent %s' % (self.opts.vec, tuple(extent)))

@@ -163,9 +163,8 @@ class StreamProgram:
     #    extent (tile_size..., rows) -- tiles are whole rows laid end to end --
     #    with the fast marching kernels (built on first use);
     #  * as the linearised 1-D program (always valid, one cell per thread).
-    self._kernel = runtime.Program(self.flat,
-                                   lower.LowerOptions(strategy='direct'),
-                                   device=device)
+    self._linear = {}      # cells per thread -> Program of the 1-D form
+    self._linear_program(1)
     self._dense = None
     if dense is None:
       dense = stencil.dim >= 2 and stencil.tile_size[0] >= self.DENSE_MIN_TILE0
@@ -219,6 +218,13 @@ class StreamProgram:
           'loading %s' % name)
       self._handles[tensor] = (h, plan)
     self._scratch = {}
+
+  def _linear_program(self, vec: int) -> 'runtime.Program':
+    if vec not in self._linear:
+      self._linear[vec] = runtime.Program(
+          self.flat, lower.LowerOptions(strategy='direct', vec=vec),
+          device=self.device)
+    return self._linear[vec]
 
   # -- device memory helpers -----------------------------------------------
   def _dev(self, key, nbytes):
@@ -274,7 +280,11 @@ class StreamProgram:
     if self._run_dense(dense_out, dense_in, n, epc[st.input_names[0]], stream):
       self.last_mode = 'dense'
     else:
-      self._kernel.run_device(dense_out, dense_in, (n,), st.iterate, stream)
+      vec = lower.default_vec(self.flat)
+      while vec > 1 and n % vec:
+        vec //= 2
+      self._linear_program(vec).run_device(dense_out, dense_in, (n,),
+                                           st.iterate, stream)
       self.last_mode = 'linear'
     for name, d in zip(st.output_names, dense_out):
       if len(out_banks[name]) != self.banks[name]:
@@ -346,9 +356,9 @@ class StreamProgram:
     for p, _ in getattr(self, '_scratch', {}).values():
       self._lib.soda_hip_free(self.device, ctypes.c_void_p(p))
     self._scratch = {}
-    if getattr(self, '_kernel', None):
-      self._kernel.close()
-      self._kernel = None
+    for prog in getattr(self, '_linear', {}).values():
+      prog.close()
+    self._linear = {}
     if getattr(self, '_dense', None):
       self._dense.close()
       self._dense = None
