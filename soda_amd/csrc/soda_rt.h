@@ -377,3 +377,12 @@ SODA_DEV void soda_buf_store_frag(soda_rsrc_t r, unsigned off,
     __builtin_amdgcn_raw_buffer_store_b8(t, r, off, 0, kAux);
   }
 }
+
+// ---- stage-pipelined blocks ------------------------------------------------
+// One barrier per row step: every LDS access this wave has issued has
+// completed (lgkmcnt(0)) before any wave of the block starts the next step.
+// Deliberately NOT __syncthreads(): a workgroup fence would also drain vmcnt,
+// i.e. wait for the global prefetch loads the first wave keeps in flight.
+SODA_DEV void soda_pipe_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}

@@ -443,3 +443,27 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
     assert np.array_equal(got[o], want[o]), o
   lo, hi = stencil.valid_box(extent)
   assert all(h > l for l, h in zip(lo, hi))
+
+
+@pytest.mark.parametrize('name,iterate,fuse,pipe,extent', [
+    ('jacobi2d.soda', 12, 12, 4, (1000, 333)),
+    ('jacobi2d.soda', 12, 12, 2, (520, 97)),
+    ('jacobi2d.soda', 12, 12, 3, (256, 64)),
+    ('jacobi2d.soda', 14, 12, 6, (777 * 4, 41)),     # 12 pipelined + 2 single
+    ('seidel2d.soda', 8, 8, 4, (640, 200)),
+    ('blur.soda', 4, 4, 2, (640, 200)),              # two stages per iteration
+    ('blur.soda', 6, 6, 3, (1024, 50)),
+    ('coupled2d.soda', 4, 4, 2, (300, 90)),          # 2 tensors cross per wave
+    ('coupled2d.soda', 6, 6, 3, (300, 90)),
+])
+def test_stage_pipelined_blocks(built, name, iterate, fuse, pipe, extent):
+  """The fused iterations split over the waves of a block (rows handed from
+  wave to wave through an LDS ring, one barrier per row step): bit-identical
+  to the oracle, like the one-wave kernels."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  opts = lower.LowerOptions(fuse=(fuse,), pipe=pipe)
+  mod = lower.lower(stencil, lower.LowerOptions(fuse=(fuse,), pipe=pipe, vec=4))
+  assert any('_pipe%d' % pipe in k.name for k in mod.kernels)
+  _check(stencil, extent, opts, oracle='c')

@@ -15,6 +15,10 @@ ap.add_argument('--iterate', type=int, default=None)
 ap.add_argument('--fuse', type=int, nargs='*', default=[])
 ap.add_argument('--strategy', default='auto')
 ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--pipe', type=int, default=1)
+ap.add_argument('--pipe-rows', type=int, default=2)
+ap.add_argument('--shift', default='dpp')
+ap.add_argument('--chunk', type=int, default=0)
 args = ap.parse_args()
 path = args.soda if os.path.exists(args.soda) else os.path.join(ROOT, 'tests/golden/soda', args.soda)
 st = core.from_file(path, iterate=args.iterate)
@@ -23,7 +27,7 @@ shape = tuple(args.extent[::-1])
 dev = torch.device('cuda', 0)
 ins = [torch.rand(shape, device=dev, dtype=T[t.np_name]) if T[t.np_name].is_floating_point else torch.randint(0, 200, shape, device=dev, dtype=T[t.np_name]) for t in st.input_types]
 outs = [torch.empty(shape, device=dev, dtype=T[t.np_name]) for t in st.output_types]
-prog = runtime.Program(st, lower.LowerOptions(strategy=args.strategy, fuse=tuple(args.fuse)), extent=args.extent)
+prog = runtime.Program(st, lower.LowerOptions(strategy=args.strategy, fuse=tuple(args.fuse), pipe=args.pipe, pipe_rows=args.pipe_rows, lane_shift=args.shift, chunk_rows=args.chunk or None), extent=args.extent)
 s = torch.cuda.current_stream().cuda_stream
 a, b = runtime.Event(), runtime.Event()
 prog.run_device([t.data_ptr() for t in outs], [t.data_ptr() for t in ins], args.extent, stream=s)
