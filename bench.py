@@ -48,6 +48,8 @@ def parse_args():
   ap.add_argument('--prefetch', type=int, default=None)
   ap.add_argument('--waves-x', type=int, default=1)
   ap.add_argument('--waves-y', type=int, default=1)
+  ap.add_argument('--pipe', type=int, default=1,
+                  help='wavefronts per block sharing the fused iterations')
   ap.add_argument('--strategy', default='auto')
   ap.add_argument('--exchange-every', type=int, default=0,
                   help='iterations between halo exchanges (N > 1); 0 = auto: '
@@ -173,7 +175,7 @@ def main():
                               fuse=tuple(f for f in fuse_list if f > 1),
                               chunk_rows=args.chunk_rows,
                               prefetch=args.prefetch, waves_x=args.waves_x,
-                              waves_y=args.waves_y)
+                              waves_y=args.waves_y, pipe=args.pipe)
 
   prog = runtime.Program(stencil, options(fuses), device=local_rank,
                          extent=local_extent)

@@ -50,6 +50,10 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-waves', type=str, dest='hip_waves', default='1x1',
                       metavar='XxY', help='wavefronts per block along '
                       'dimension 0 and 1')
+  parser.add_argument('--hip-pipe', type=int, dest='hip_pipe', default=1,
+                      metavar='W', help='split the fused iterations of a 2-D '
+                      'kernel over W wavefronts of a block (rows handed on '
+                      'through LDS); the fusion depth must be a multiple')
   parser.add_argument('--hip-nt-store', action='store_true',
                       dest='hip_nt_store',
                       help='non-temporal instead of plain output stores')
@@ -72,7 +76,8 @@ def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
                             nt_store=True if args.hip_nt_store else None,
                             nt_load=False if args.hip_no_nt_load else None,
                             tile_rows=args.hip_tile_rows,
-                            xcd_swizzle=not args.hip_no_xcd_swizzle)
+                            xcd_swizzle=not args.hip_no_xcd_swizzle,
+                            pipe=args.hip_pipe)
 
 
 def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
