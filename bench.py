@@ -48,7 +48,7 @@ def parse_args():
   ap.add_argument('--prefetch', type=int, default=None)
   ap.add_argument('--waves-x', type=int, default=1)
   ap.add_argument('--waves-y', type=int, default=1)
-  ap.add_argument('--pipe', type=int, default=1,
+  ap.add_argument('--pipe', type=int, default=None,
                   help='wavefronts per block sharing the fused iterations')
   ap.add_argument('--strategy', default='auto')
   ap.add_argument('--exchange-every', type=int, default=0,

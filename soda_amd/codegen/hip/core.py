@@ -50,10 +50,11 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-waves', type=str, dest='hip_waves', default='1x1',
                       metavar='XxY', help='wavefronts per block along '
                       'dimension 0 and 1')
-  parser.add_argument('--hip-pipe', type=int, dest='hip_pipe', default=1,
+  parser.add_argument('--hip-pipe', type=int, dest='hip_pipe', default=None,
                       metavar='W', help='split the fused iterations of a 2-D '
                       'kernel over W wavefronts of a block (rows handed on '
-                      'through LDS); the fusion depth must be a multiple')
+                      'through LDS); the fusion depth must be a multiple '
+                      '(default 1)')
   parser.add_argument('--hip-nt-store', action='store_true',
                       dest='hip_nt_store',
                       help='non-temporal instead of plain output stores')

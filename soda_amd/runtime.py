@@ -333,6 +333,14 @@ def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
   along = max(1, tune['waves_along'])
   across = waves_per_block // along      # waves of a block side by side
   warm = tune['warm']
+  if tune.get('pipe', 1) > 1:
+    # Stage-pipelined blocks: the warm-up is paid once per block and the waves
+    # of a block keep each other busy, so the best chunk hardly depends on the
+    # grid: ~3.5x the warm-up (T=12, 4 waves: 96-128 rows is best or within 2 %
+    # of it on 8192 x {8192, 4296, 2248, 1224}; profiles/r01_sweep_pipe_chunk)
+    target = max(64, int(3.5 * warm))
+    chunks = max(1, -(-n // target))
+    return max(1, -(-n // chunks))
   k_min = 4 if warm <= 12 else 2
   simds = NUM_CUS * 4
   best = None
