@@ -27,1238 +27,25 @@ GPU.  Two families of kernels are generated:
 
 Floating-point results are bit-identical to the CPU oracle because the kernels
 compile the same C expression text with -ffp-contract=off.
+
+Layout of the package: module.py (Module, descriptors, the device runtime
+text), march.py (`march2d` / `march3d`), direct.py, lds2d.py (the classic LDS
+halo tile, kept as the measured alternative); this file holds the options and
+`lower()`, which picks the shape.
 """
-import os
-from typing import Dict, List, Optional, Sequence, Tuple
-
-from soda_amd import core, ir, util
-
-_HERE = os.path.dirname(os.path.abspath(__file__))
-_RT_PATH = os.path.join(_HERE, '..', '..', 'csrc', 'soda_rt.h')
-_COORDS = util.COORDS_IN_ORIG
-
-MAX_UNROLL = 24        # tallest register window (planes) a marching wave holds
-MAX_FUSE_3D = 2            # deepest temporal blocking of the 3-D kernels
-MAX_SHIFT_TEMPS = 64       # lane-shifted operand copies per row step
-REG_BUDGET = 160           # estimated VGPRs (windows + shifted copies) a shape may need
-
-
-def runtime_text() -> str:
-  with open(_RT_PATH) as f:
-    return f.read()
-
-
-class KernelDesc:
-  """Mirror of soda_hip_kernel_desc_t."""
-
-  def __init__(self, name: str, block: Sequence[int], tile: Sequence[int],
-               lds_bytes: int = 0, note: str = '',
-               tune: Optional[dict] = None):
-    self.name = name
-    self.block = tuple(block) + (1,) * (3 - len(block))
-    self.tile = tuple(tile) + (1,) * (util.MAX_DIM - len(tile))
-    self.lds_bytes = lds_bytes
-    self.note = note
-    # marching kernels: what the host needs to size the chunk length at load
-    # time (axis, waves of a block along it, pipeline warm-up, fixed or not)
-    self.tune = tune
-
-
-class PassDesc:
-  """Mirror of soda_hip_pass_desc_t (kernel indices are into Module.kernels)."""
-
-  def __init__(self, fused_iters: int, kernels: Sequence[int], kind: str,
-               traffic_model: Optional[dict] = None):
-    self.fused_iters = fused_iters
-    self.kernels = list(kernels)
-    self.kind = kind
-    self.traffic_model = traffic_model or {}
-
-
-class Module:
-  """HIP source text + plan for one program at one vector width."""
-
-  def __init__(self, stencil: core.Stencil):
-    self.stencil = stencil
-    self.chunks: List[str] = []
-    self.kernels: List[KernelDesc] = []
-    self.passes: List[PassDesc] = []
-    names = list(stencil.input_names) + list(stencil.output_names) + list(
-        stencil.local_names)
-    self.slot = {n: i for i, n in enumerate(names)}
-    table = stencil.symbol_table
-    self.elem_size = [table[n].size_in_bytes for n in names]
-
-  def add_kernel(self, desc: KernelDesc, text: str) -> int:
-    self.kernels.append(desc)
-    self.chunks.append(text)
-    return len(self.kernels) - 1
-
-  @property
-  def source(self) -> str:
-    head = ('// generated by soda_amd (sodac --hip-kernel) for `%s`; gfx950 only\n'
-            % self.stencil.app_name)
-    st = self.stencil
-    types = [s.haoda_type for s in
-             st.input_stmts + st.local_stmts + st.output_stmts]
-    for s in st.local_stmts + st.output_stmts:
-      types += [l.haoda_type for l in s.let if l.haoda_type is not None]
-    text = ' '.join(str(s) for s in st.local_stmts + st.output_stmts)
-    if all(t.width_in_bits <= 32 for t in types) and 'double' not in text \
-        and 'int64' not in text:
-      # no 64-bit arithmetic anywhere: fp32 lane shifts may fold into their
-      # consumers (soda_rt.h, soda_lane_shift)
-      head += '#define SODA_FOLD_F32_DPP 1\n'
-    return head + runtime_text() + '\n' + '\n'.join(self.chunks)
-
-  def sorted_passes(self) -> List[PassDesc]:
-    return sorted(self.passes, key=lambda p: -p.fused_iters)
-
-
-def _check_native(stencil: core.Stencil) -> None:
-  if stencil.param_stmts:
-    raise util.SemanticError(
-        'the HIP backend does not support `param` tensors yet')
-  for stmt in stencil.input_stmts + stencil.local_stmts + stencil.output_stmts:
-    if not stmt.haoda_type.is_native:
-      raise util.SemanticError(
-          'the HIP backend runs 8/16/32/64-bit integers, float and double; '
-          '`%s` is %s' % (stmt.name, stmt.haoda_type))
-    for let in getattr(stmt, 'let', ()):
-      if let.haoda_type is not None and not let.haoda_type.is_native:
-        raise util.SemanticError('let `%s` has unsupported type %s' %
-                                 (let.name, let.haoda_type))
-
-
-# ---------------------------------------------------------------------------
-# direct kernels
-# ---------------------------------------------------------------------------
-
-DIRECT_BLOCK = 256
-
-
-def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
-                        vec: int) -> Tuple[List[str], Tuple[int, ...]]:
-  """`direct` with `vec` cells per thread: every row of a parent the stage taps
-  is fetched ONCE per thread into registers (span of the taps + vec - 1 cells)
-  and shared by the thread's cells; the expression is emitted operation-major
-  (ir.c_statements) so a row is fetched right before its first use and dies
-  after its last.  contrast (17 x 17 taps): 289 loads per cell -> <= 18 per
-  row per 4 cells.  Threads whose cells are not all interior along dimension 0
-  take the one-cell-at-a-time path; results are those of the scalar kernel."""
-  st = mod.stencil
-  dim = st.dim
-  table = st.symbol_table
-  parents = list(stage.taps)
-  lo = [0] * dim
-  hi = [0] * dim
-  for parent in parents:
-    tlo, thi = stage.tap_bounds(parent)
-    for d in range(dim):
-      lo[d] = max(lo[d], -tlo[d])
-      hi[d] = max(hi[d], thi[d])
-  ct = stage.haoda_type.c_type
-  V = vec
-  L = [
-      '// stage `%s`, %d cells per thread: %s' %
-      (stage.name, V, ' '.join(str(stage.stmt).split())[:400]),
-      'extern "C" __global__ void __launch_bounds__(%d) %s(soda_hip_kargs_t a) {'
-      % (DIRECT_BLOCK, name),
-      '  unsigned b = blockIdx.x;',
-      '  const int %s = ((int)(b %% (unsigned)a.ntile[0]) * %d + '
-      '(int)threadIdx.x) * %d;' % (_COORDS[0], DIRECT_BLOCK, V),
-      '  b /= (unsigned)a.ntile[0];',
-  ]
-  for d in range(1, dim):
-    L.append('  const int %s = (int)(b %% (unsigned)a.ntile[%d]); '
-             'b /= (unsigned)a.ntile[%d];' % (_COORDS[d], d, d))
-  L.append('  if (%s >= a.extent[0]) return;' % _COORDS[0])
-  L.append('  %s* __restrict__ out = (%s*)a.buf[%d];' %
-           (ct, ct, mod.slot[stage.name]))
-  for parent in parents:
-    pt = table[parent].c_type
-    L.append('  const %s* __restrict__ in_%s = (const %s*)a.buf[%d];' %
-             (pt, parent, pt, mod.slot[parent]))
-  L.append('  const int64_t soda_o = %s;' % ' + '.join(
-      ['(int64_t)%s' % _COORDS[0]] +
-      ['(int64_t)%s * a.stride[%d]' % (_COORDS[d], d) for d in range(1, dim)]))
-  outer = []
-  for d in range(1, dim):
-    if lo[d]:
-      outer.append('%s >= %d' % (_COORDS[d], lo[d]))
-    if hi[d]:
-      outer.append('%s < a.extent[%d] - %d' % (_COORDS[d], d, hi[d]))
-  L.append('  %s soda_r[%d];' % (ct, V))
-  L.append('  soda_zero_frag<%s, %d>(soda_r);' % (ct, V))
-  L.append('  const bool soda_rows_ok = %s;' %
-           (' && '.join(outer) if outer else 'true'))
-  L.append('  if (soda_rows_ok && %s >= %d && %s + %d < a.extent[0] - %d) {' %
-           (_COORDS[0], lo[0], _COORDS[0], V - 1, hi[0]))
-
-  # ---- all cells interior: shared row buffers --------------------------------
-  rows: Dict[Tuple[str, Tuple[int, ...]], Tuple[str, int]] = {}
-  spans: Dict[Tuple[str, Tuple[int, ...]], List[int]] = {}
-  for ref in ir.get_loads(stage.stmt.expr):
-    off = tuple(a - b for a, b in zip(ref.idx, stage.st_idx))
-    key = (ref.name, off[1:])
-    sp = spans.setdefault(key, [off[0], off[0]])
-    sp[0], sp[1] = min(sp[0], off[0]), max(sp[1], off[0])
-  body: List[str] = []
-
-  def mk_load(e: int):
-    def load(ref: ir.Ref) -> str:
-      off = tuple(a - b for a, b in zip(ref.idx, stage.st_idx))
-      key = (ref.name, off[1:])
-      if key not in rows:
-        mn, mx = spans[key]
-        var = 'rb%d_%s' % (len(rows), ref.name)
-        n = mx - mn + V
-        pt = table[ref.name].c_type
-        terms = ['soda_o', '(%d)' % mn]
-        for d in range(1, dim):
-          if off[d]:
-            terms.append('(%d) * a.stride[%d]' % (off[d], d))
-        body.append('%s %s[%d];' % (pt, var, n))
-        body.append('{ const %s* __restrict__ p = in_%s + (%s);' %
-                    (pt, ref.name, ' + '.join(terms)))
-        body.append('  _Pragma("unroll") for (int i = 0; i < %d; ++i) '
-                    '%s[i] = p[i]; }' % (n, var))
-        rows[key] = (var, mn)
-      var, mn = rows[key]
-      return '%s[%d]' % (var, off[0] - mn + e)
-    return load
-
-  counter = [0]
-
-  def fresh() -> str:
-    counter[0] += 1
-    return 'v%d' % counter[0]
-
-  _, results = ir.c_statements(stage.stmt.expr, [mk_load(e) for e in range(V)],
-                               fresh, stmts=body)
-  L.extend('    ' + x for x in body)
-  for e, r in enumerate(results):
-    L.append('    soda_r[%d] = (%s)(%s);' % (e, ct, r))
-  L.append('  } else if (soda_rows_ok) {')
-
-  # ---- strip ends: one cell at a time, as the scalar kernel ------------------
-  def scalar_load(ref: ir.Ref) -> str:
-    terms = ['soda_o', 'e']
-    for d in range(dim):
-      off = ref.idx[d] - stage.st_idx[d]
-      if off:
-        terms.append('(%d)' % off if d == 0 else
-                     '(%d) * a.stride[%d]' % (off, d))
-    return 'in_%s[%s]' % (ref.name, ' + '.join(terms))
-
-  L.append('    _Pragma("unroll") for (int e = 0; e < %d; ++e) {' % V)
-  L.append('      if (%s + e >= %d && %s + e < a.extent[0] - %d)' %
-           (_COORDS[0], lo[0], _COORDS[0], hi[0]))
-  L.append('        soda_r[e] = (%s)(%s);' %
-           (ct, ir.c_expr(stage.stmt.expr, scalar_load)))
-  L.append('    }')
-  L.append('  }')
-  L.append('  soda_store_frag<%s, %d, false>(out + soda_o, soda_r);' % (ct, V))
-  L.append('}')
-  return L, (DIRECT_BLOCK * V,) + (1,) * (dim - 1)
-
-
-def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
-  st = mod.stencil
-  dim = st.dim
-  table = st.symbol_table
-  kernel_ids = []
-  for stage in st.ordered_stages:
-    name = '%s_direct_%s' % (st.app_name, stage.name)
-    if vec > 1 and not stage.stmt.let and stage.taps:
-      lines, tile = _direct_rows_kernel(mod, stage, name + '_v%d' % vec, vec)
-      kernel_ids.append(mod.add_kernel(
-          KernelDesc(name + '_v%d' % vec, (DIRECT_BLOCK, 1, 1), tile,
-                     note='direct rows V%d' % vec), '\n'.join(lines) + '\n'))
-      continue
-    parents = list(stage.taps)
-    lo = [0] * dim
-    hi = [0] * dim
-    for parent in parents:
-      tlo, thi = stage.tap_bounds(parent)
-      for d in range(dim):
-        lo[d] = max(lo[d], -tlo[d])
-        hi[d] = max(hi[d], thi[d])
-    lines = [
-        '// stage `%s`: %s' % (stage.name,
-                               ' '.join(str(stage.stmt).split())),
-        'extern "C" __global__ void __launch_bounds__(%d) %s(soda_hip_kargs_t a) {'
-        % (DIRECT_BLOCK, name),
-        '  unsigned b = blockIdx.x;',
-        '  const int %s = (int)(b %% (unsigned)a.ntile[0]) * %d + (int)threadIdx.x;'
-        % (_COORDS[0], DIRECT_BLOCK),
-        '  b /= (unsigned)a.ntile[0];',
-    ]
-    for d in range(1, dim):
-      lines.append('  const int %s = (int)(b %% (unsigned)a.ntile[%d]); '
-                   'b /= (unsigned)a.ntile[%d];' % (_COORDS[d], d, d))
-    lines.append('  if (%s >= a.extent[0]) return;' % _COORDS[0])
-    ct = stage.haoda_type.c_type
-    lines.append('  %s* __restrict__ out = (%s*)a.buf[%d];' %
-                 (ct, ct, mod.slot[stage.name]))
-    for parent in parents:
-      pt = table[parent].c_type
-      lines.append('  const %s* __restrict__ in_%s = (const %s*)a.buf[%d];' %
-                   (pt, parent, pt, mod.slot[parent]))
-    lines.append('  const int64_t soda_o = %s;' % ' + '.join(
-        ['(int64_t)%s' % _COORDS[0]] +
-        ['(int64_t)%s * a.stride[%d]' % (_COORDS[d], d) for d in range(1, dim)]))
-    conds = []
-    for d in range(dim):
-      if lo[d]:
-        conds.append('%s >= %d' % (_COORDS[d], lo[d]))
-      if hi[d]:
-        conds.append('%s < a.extent[%d] - %d' % (_COORDS[d], d, hi[d]))
-    lines.append('  %s soda_r = (%s)0;' % (ct, ct))
-    lines.append('  if (%s) {' % (' && '.join(conds) if conds else 'true'))
-
-    def load(ref: ir.Ref, _stage=stage) -> str:
-      terms = ['soda_o']
-      for d in range(dim):
-        off = ref.idx[d] - _stage.st_idx[d]
-        if off:
-          terms.append('(%d)' % off if d == 0 else
-                       '(%d) * a.stride[%d]' % (off, d))
-      return 'in_%s[%s]' % (ref.name, ' + '.join(terms))
-
-    for let in stage.stmt.let:
-      lines.append('    const %s %s = %s;' %
-                   (let.haoda_type.c_type, let.name, ir.c_expr(let.expr, load)))
-    lines.append('    soda_r = (%s)(%s);' % (ct, ir.c_expr(stage.stmt.expr, load)))
-    lines.append('  }')
-    lines.append('  out[soda_o] = soda_r;')
-    lines.append('}')
-    kernel_ids.append(
-        mod.add_kernel(
-            KernelDesc(name, (DIRECT_BLOCK, 1, 1), (DIRECT_BLOCK,) + (1,) *
-                       (dim - 1), note='direct'), '\n'.join(lines) + '\n'))
-  # traffic: every stage reads its parents once (ideal caching) and writes once
-  p = PassDesc(1, kernel_ids, 'direct')
-  mod.passes.append(p)
-  return p
-
-
-# ---------------------------------------------------------------------------
-# march: register-window marching along the last (streamed) dimension
-# ---------------------------------------------------------------------------
-
-class _Node:
-  """A tensor of the T-times unrolled chain."""
-
-  def __init__(self, key, ctype: str, stage: Optional[core.Stage], it: int):
-    self.key = key              # ('in', name) or (stage name, iteration)
-    self.ctype = ctype
-    self.stage = stage          # None for a global input
-    self.it = it
-    self.parents: Dict[str, '_Node'] = {}   # DSL name -> node
-    self.delay = 0              # ticks between issue of input plane t and plane t here
-    self.window = 1             # planes (rows in 2-D) kept
-    self.slots = 1              # window padded to a divisor of the unroll
-    self.margin = [0, 0]        # invalid cells at the low/high end of a strip
-    self.rmargin = [0, 0]       # 3-D: invalid rows at the low/high end of a tile
-    self.store_slot: Optional[int] = None   # plan slot if stored to memory
-    # stage-pipelined blocks: the wave that owns (computes / loads) the tensor;
-    # a `mirror` is the copy a wave keeps of a tensor the previous wave of the
-    # block produces, filled from the LDS ring one tick after its production
-    self.owner = 0
-    self.mirror_of: Optional['_Node'] = None
-    self.to_lds = False         # some wave mirrors this tensor
-
-  @property
-  def is_input(self) -> bool:
-    return self.stage is None and self.mirror_of is None
-
-  @property
-  def fill_delay(self) -> int:
-    """Ticks between the issue of input plane t and the tick at which plane t
-    of THIS tensor is put into its register slot (loaded, read from LDS or
-    computed).  Loads are put in flight `delay` ticks before they are used."""
-    if self.mirror_of is not None:
-      return self.delay - MIRROR_PREFETCH
-    return 0 if self.stage is None else self.delay
-
-  @property
-  def var(self) -> str:
-    if self.mirror_of is not None:
-      return 'm%d_%s' % (self.owner, self.mirror_of.var)
-    if self.stage is None:
-      return 'g_%s' % self.key[1]
-    return 't%d_%s' % (self.it, self.stage.name)
-
-
-LDS_PER_CU = 160 * 1024     # MI355X_MICROARCH.md
-MIRROR_PREFETCH = 1         # ticks between a mirror's LDS read and its first use
-
-
-class MarchConfig:
-
-  def __init__(self, fused_iters: int = 1, vec: int = 4, chunk_rows: int = 64,
-               prefetch: int = 2, waves_x: int = 1, waves_y: int = 1,
-               nt_store: bool = False, nt_load: bool = True,
-               xcd_swizzle: bool = True, edge_loads: bool = True,
-               tile_rows: int = 6, warm_guards: bool = False,
-               interleave: bool = False, lane_shift: str = 'dpp',
-               min_waves: int = 0, occupancy: int = 0,
-               buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4):
-    # row steps per barrier of a stage-pipelined block (power of two): the
-    # waves synchronise once per `pipe_rows` rows through a ring of twice
-    # that many slots
-    self.pipe_rows = pipe_rows if pipe > 1 else 1
-    # stage-pipelined blocks: the fused iterations are split over `pipe` waves
-    # of a block; wave w runs iterations [w*T/pipe, (w+1)*T/pipe) of the SAME
-    # strip and chunk one tick behind wave w-1, rows travel through a 2-slot
-    # LDS ring, one barrier per tick.  Fewer registers per wave (more waves per
-    # SIMD) and `pipe` times longer chunks for the same number of waves (the
-    # 2T-row warm-up is paid per block, not per wave).
-    self.pipe = pipe
-    # vector memory through buffer resources with out-of-range offsets instead
-    # of `if (row_ok)` branches (soda_rt.h): straight-line loop body, exact
-    # s_waitcnt counts
-    self.buffer_ops = buffer_ops
-    # cap the waves resident per SIMD (0 = whatever the registers allow) by
-    # giving every block an LDS allocation it never touches: 3 waves per SIMD
-    # issue VALU work slower than 2 or 4 (tools/valubench.py)
-    self.occupancy = occupancy
-    # ask the register allocator for at least this many waves per SIMD
-    # (amdgpu_waves_per_eu); 0 = let it use what it wants
-    self.min_waves = min_waves
-    # how a row is shifted by one lane: 'dpp' (wave_shr/shl fused into the
-    # consuming add) or 'bperm' (ds_bpermute_b32, issued one stage early)
-    self.lane_shift = lane_shift
-    # emit a stage's cells operation-major (independent statements back to
-    # back).  Measured SLOWER on gfx950 (T=12: 186 vs 151 us): a wave64 VALU op
-    # runs as two 32-lane passes, so a dependent op already issues without a
-    # bubble, and the interleaved order only adds register-bank pressure.
-    self.interleave = interleave
-    self.warm_guards = warm_guards  # skip a stage while its rows cannot
-    #                                 reach any output row of this chunk yet
-    self.fused_iters = fused_iters
-    self.vec = vec
-    self.chunk_rows = chunk_rows  # cells one wave marches over (last dim)
-    self.prefetch = prefetch
-    self.waves_x = waves_x
-    self.waves_y = waves_y
-    self.nt_store = nt_store      # non-temporal stores of the output rows
-    self.nt_load = nt_load        # non-temporal loads of the input rows
-    self.xcd_swizzle = xcd_swizzle  # neighbouring tiles on one XCD (one L2)
-    self.edge_loads = edge_loads  # halo cells of the inputs fetched by the
-    #                               strip's edge lanes instead of overlap
-    self.tile_rows = tile_rows    # 3-D: output rows (dim 1) per wave
-    self.chunk_fixed = False      # True: the host must not re-size the chunk
-
-  def key(self) -> str:
-    # chunk_rows is a launch-time value, not part of the code
-    return 'T%d_V%d_P%d_W%dx%d_R%d%s%s%s%s' % (
-        self.fused_iters, self.vec, self.prefetch,
-        self.waves_x, self.waves_y, self.tile_rows,
-        '_nts' if self.nt_store else '', '_ntl' if self.nt_load else '',
-        '_xcd' if self.xcd_swizzle else '',
-        '_edge' if self.edge_loads else '') + (
-            '_wg' if self.warm_guards else '') + (
-                '_il' if self.interleave else '') + (
-                    '_bp' if self.lane_shift == 'bperm' else
-                    '_noshift' if self.lane_shift == 'none' else '') + (
-                        '_mw%d' % self.min_waves if self.min_waves else '') + (
-                            '_occ%d' % self.occupancy if self.occupancy else '') + (
-                                '_buf' if self.buffer_ops else '') + (
-                                    '_pipe%dx%d' % (self.pipe, self.pipe_rows)
-                                    if self.pipe > 1 else '')
-
-
-March2DConfig = MarchConfig   # older name
-
-
-def default_vec(stencil: core.Stencil) -> int:
-  """16 bytes per lane per row for the widest tensor."""
-  widest = max(t.size_in_bytes for t in stencil.symbol_table.values())
-  return max(1, 16 // widest)
-
-
-def march_supported(stencil: core.Stencil) -> Optional[str]:
-  """None if the marching kernels can run the program, else why not."""
-  if stencil.dim not in (2, 3):
-    return 'the marching kernels need a 2- or 3-dimensional program'
-  if stencil.param_stmts:
-    return 'param tensors'
-  return None
-
-
-march2d_supported = march_supported
-
-
-def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
-                 pipe: int = 1, pipe_rows: int = 1):
-  """The tensors of T chained iterations with their schedule (delay in ticks
-  behind the load of the input plane, window of planes kept, invalid margins).
-  `pipe` > 1 splits the iterations evenly over that many waves of a block:
-  a tensor consumed by the next wave gets a mirror there (see _Node)."""
-  dim = st.dim
-  ax = dim - 1                         # march axis
-  table = st.symbol_table
-  per_wave = T // pipe
-  nodes: List[_Node] = []
-  inputs = {}
-  for name in st.input_names:
-    n = _Node(('in', name), table[name].c_type, None, -1)
-    n.delay = pf
-    n.margin = [-edge[0], -edge[1]]    # edge lanes fetch that many halo cells
-    inputs[name] = n
-    nodes.append(n)
-  cur_inputs = dict(inputs)
-  last_outputs = {}
-  for it in range(T):
-    owner = it // per_wave if pipe > 1 else 0
-    env = {}
-    for name, src in cur_inputs.items():
-      if src.owner != owner:
-        m = _Node(('mirror', src.key, owner), src.ctype, None, it)
-        m.mirror_of = src
-        m.owner = owner
-        src.to_lds = True
-        nodes.append(m)
-        src = m
-      env[name] = src
-    for stage in st.ordered_stages:
-      n = _Node((stage.name, it), stage.haoda_type.c_type, stage, it)
-      n.owner = owner
-      for parent in stage.taps:
-        n.parents[parent] = env[parent]
-      env[stage.name] = n
-      nodes.append(n)
-    last_outputs = {o: env[o] for o in st.output_names}
-    if it < T - 1:
-      cur_inputs = {i: env[o] for i, o in zip(st.input_names, st.output_names)}
-  # delays and margins, in chain order
-  for n in nodes:
-    if n.mirror_of is not None:
-      src = n.mirror_of
-      # read `pipe_rows` ticks (one barrier period) after it was written, used
-      # MIRROR_PREFETCH ticks after that
-      n.delay = src.delay + pipe_rows + MIRROR_PREFETCH
-      n.margin = list(src.margin)
-      n.rmargin = list(src.rmargin)
-      continue
-    if n.stage is None:
-      continue
-    delay = None
-    margin = [0, 0]
-    rmargin = [0, 0]
-    for pname, p in n.parents.items():
-      tlo, thi = n.stage.tap_bounds(pname)
-      d = p.delay + thi[ax]
-      delay = d if delay is None else max(delay, d)
-      margin[0] = max(margin[0], p.margin[0] + max(0, -tlo[0]))
-      margin[1] = max(margin[1], p.margin[1] + max(0, thi[0]))
-      if dim == 3:
-        rmargin[0] = max(rmargin[0], p.rmargin[0] + max(0, -tlo[1]))
-        rmargin[1] = max(rmargin[1], p.rmargin[1] + max(0, thi[1]))
-    n.delay = delay if delay is not None else 0
-    n.margin = margin
-    n.rmargin = rmargin
-  # windows: a parent keeps planes from its newest (age 0) to the oldest any
-  # child still reads
-  for n in nodes:
-    if n.stage is None:
-      continue
-    for pname, p in n.parents.items():
-      tlo, _ = n.stage.tap_bounds(pname)
-      p.window = max(p.window, n.delay - tlo[ax] - p.fill_delay + 1)
-  return nodes, inputs, last_outputs
-
-
-def _choose_unroll(nodes: List[_Node], regs_per_plane: int,
-                   multiple_of: int = 1) -> Optional[int]:
-  max_w = max(n.window for n in nodes)
-  best = None
-  for u in range(max_w, MAX_UNROLL + 1):
-    if u % multiple_of:
-      continue
-    divisors = [d for d in range(1, u + 1) if u % d == 0]
-    pad = 0
-    for n in nodes:
-      slots = min(d for d in divisors if d >= n.window)
-      pad += slots - n.window
-    cost = pad * regs_per_plane + 2 * u
-    if best is None or cost < best[0]:
-      best = (cost, u)
-  return None if best is None else best[1]
-
-
-def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
-  st = mod.stencil
-  why = march_supported(st)
-  if why:
-    raise util.SemanticError('march: %s' % why)
-  dim = st.dim
-  ax = dim - 1
-  T, V, PF = cfg.fused_iters, cfg.vec, cfg.prefetch
-  if T > 1 and len(st.input_names) != len(st.output_names):
-    raise util.SemanticError('march: cannot fuse iterations of a program '
-                             'whose inputs and outputs differ in number')
-  # halo cells of the program inputs that the strip's edge lanes fetch with
-  # separate narrow loads (so a 1-iteration strip keeps all 64 lanes valid and
-  # its rows start on a 64*V-cell boundary)
-  edge = (0, 0)
-  if cfg.edge_loads:
-    lo = hi = 0
-    for stage in st.ordered_stages:
-      for pname in stage.taps:
-        if pname in st.input_names:
-          tlo, thi = stage.tap_bounds(pname)
-          lo, hi = max(lo, -tlo[0]), max(hi, thi[0])
-    if max(lo, hi) <= min(V, 2):
-      edge = (lo, hi)
-  W = cfg.pipe
-  if W > 1:
-    if dim != 2 or T % W or not cfg.buffer_ops or \
-        cfg.waves_x * cfg.waves_y != 1:
-      raise util.SemanticError(
-          'march: %d pipelined waves need a 2-D program, a fusion depth that '
-          'is a multiple of it, buffer addressing and one strip per block' % W)
-    edge = (0, 0)
-  R = cfg.pipe_rows if W > 1 else 1
-  if R & (R - 1):
-    raise util.SemanticError('march: rows per barrier must be a power of two')
-  nodes, inputs, outputs = _build_chain(st, T, PF, edge, W, R)
-  out_nodes = list(outputs.values())
-  margin_lo = max(0, max(n.margin[0] for n in out_nodes))
-  margin_hi = max(0, max(n.margin[1] for n in out_nodes))
-  lanes_lo = -(-margin_lo // V)
-  lanes_hi = -(-margin_hi // V)
-  if edge != (0, 0):
-    # edge loads only pay when they save a halo lane
-    plain = _build_chain(st, T, PF, (0, 0), W, R)[2]
-    p_lo = -(-max(n.margin[0] for n in plain.values()) // V)
-    p_hi = -(-max(n.margin[1] for n in plain.values()) // V)
-    if (p_lo, p_hi) == (lanes_lo, lanes_hi):
-      edge = (0, 0)
-      nodes, inputs, outputs = _build_chain(st, T, PF, edge, W, R)
-      out_nodes = list(outputs.values())
-  if lanes_lo + lanes_hi >= 32:
-    raise util.SemanticError('march: halo of %d+%d cells is too wide for a '
-                             '64-lane strip at %d cells per lane' %
-                             (margin_lo, margin_hi, V))
-  # 3-D: rows (dim 1) of a tile held in registers
-  if dim == 3:
-    rhalo_lo = max(n.rmargin[0] for n in out_nodes)
-    rhalo_hi = max(n.rmargin[1] for n in out_nodes)
-    rows_in = cfg.tile_rows + rhalo_lo + rhalo_hi
-  else:
-    rhalo_lo = rhalo_hi = 0
-    rows_in = 1
-  tile_rows = rows_in - rhalo_lo - rhalo_hi
-  U = _choose_unroll(nodes, V * rows_in, R)
-  if U is None:
-    raise util.SemanticError(
-        'march: a tensor needs a window of %d planes (> %d)' %
-        (max(n.window for n in nodes), MAX_UNROLL))
-  for n in nodes:
-    n.slots = min(d for d in range(1, U + 1) if U % d == 0 and d >= n.window)
-  est_regs = max(
-      sum(n.slots * V * max(0, rows_in - n.rmargin[0] - n.rmargin[1])
-          for n in nodes if n.owner == wv) for wv in range(W))
-  if est_regs > 400:
-    raise util.SemanticError(
-        'march: the register windows need about %d VGPRs per lane' % est_regs)
-  for o, n in outputs.items():
-    n.store_slot = mod.slot[o]
-
-  # lowest plane of every tensor (relative to the chunk's first output plane)
-  # that some output plane of the chunk depends on: before that, computing the
-  # tensor is wasted pipeline warm-up
-  back_lo = {id(n): None for n in nodes}
-  for n in out_nodes:
-    back_lo[id(n)] = 0
-  for n in reversed(nodes):
-    if n.stage is None or back_lo[id(n)] is None:
-      continue
-    for pname, pnode in n.parents.items():
-      tlo, _ = n.stage.tap_bounds(pname)
-      cand = back_lo[id(n)] + tlo[ax]
-      if back_lo[id(pnode)] is None or cand < back_lo[id(pnode)]:
-        back_lo[id(pnode)] = cand
-
-  strip_lanes = 64 - lanes_lo - lanes_hi
-  strip_cells = strip_lanes * V
-  max_delay = max(n.delay for n in out_nodes)
-  bounds = st.window_bounds(T)
-  m_lo = min(0, min(bounds[o][0][ax] for o in st.output_names))
-  m_hi = max(0, max(bounds[o][1][ax] for o in st.output_names))
-  # load-only ticks at the head of a chunk (buffer addressing only: the peeled
-  # loads must not need branches)
-  # A stage that lags the loads by d computes, in the first `lead` <= d ticks,
-  # only planes below every plane the chunk needs; a stage without inputs
-  # (a constant) has d = 0 and forbids the peeling.
-  lead = 0
-  if cfg.buffer_ops:
-    lead = min([PF] + [n.delay for n in nodes if n.stage is not None])
-  warm = max_delay - m_lo - lead   # compute ticks before a chunk's first output
-
-  kind = 'march%dd' % dim
-  name = '%s_%s_%s' % (st.app_name, kind, cfg.key())
-  waves = cfg.waves_x * cfg.waves_y if dim == 2 else 1
-  wx = cfg.waves_x if dim == 2 else 1
-  if W > 1:
-    waves = W
-  block = 64 * waves
-  L: List[str] = []
-  w = L.append
-  w('// %s: T=%d fused iteration(s), %d cells/lane, chunks of %d along dim %d,'
-    ' prefetch %d, unroll %d' % (kind, T, V, cfg.chunk_rows, ax, PF, U))
-  w('// strip: %d lanes valid of 64 (halo %d+%d cells, edge loads %d+%d); '
-    'pipeline depth %d' % (strip_lanes, margin_lo, margin_hi, edge[0], edge[1],
-                           warm))
-  if dim == 3:
-    w('// tile: %d rows held in registers for %d output rows (halo %d+%d)' %
-      (rows_in, tile_rows, rhalo_lo, rhalo_hi))
-  for n in nodes:
-    w('//   %-24s delay %2d  window %2d (slots %2d)  margin %d/%d  rows %d/%d' %
-      (n.var, n.delay, n.window, n.slots, n.margin[0], n.margin[1],
-       n.rmargin[0], n.rmargin[1]))
-  w('extern "C" __global__ void __launch_bounds__(%d) %s%s(soda_hip_kargs_t a) {'
-    % (block, '__attribute__((amdgpu_waves_per_eu(%d, %d))) ' %
-       (cfg.min_waves, max(cfg.min_waves, 8)) if cfg.min_waves else '', name))
-  w('  const int lane = (int)(threadIdx.x & 63u);')
-  w('  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));')
-  if cfg.xcd_swizzle:
-    # blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
-    # run of tiles so halo rows/columns shared by neighbours hit one L2
-    # (speed only; any placement is correct)
-    w('  const unsigned nblk = gridDim.x;')
-    w('  const unsigned bid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u)'
-      ' + blockIdx.x / 8u : blockIdx.x;')
-  else:
-    w('  const unsigned bid = blockIdx.x;')
-  w('  const int tile_x = (int)(bid % (unsigned)a.ntile[0]);')
-  if dim == 2:
-    w('  const int tile_m = (int)(bid / (unsigned)a.ntile[0]);')
-    if W > 1:        # all waves of the block share the strip and the chunk
-      w('  const int strip = tile_x;')
-      w('  const int chunk = tile_m;')
-    else:
-      w('  const int strip = tile_x * %d + wave %% %d;' % (wx, wx))
-      w('  const int chunk = tile_m * %d + wave / %d;' % (cfg.waves_y, wx))
-    w('  const int n0 = a.extent[0], nm = a.extent[1];')
-  else:
-    w('  const int tile_y = (int)((bid / (unsigned)a.ntile[0]) % '
-      '(unsigned)a.ntile[1]);')
-    w('  const int chunk = (int)(bid / ((unsigned)a.ntile[0] * '
-      '(unsigned)a.ntile[1]));')
-    w('  const int strip = tile_x;')
-    w('  const int n0 = a.extent[0], n1 = a.extent[1], nm = a.extent[2];')
-    w('  const int y0 = tile_y * %d - %d;  // first row held' %
-      (tile_rows, rhalo_lo))
-    w('  const int64_t pitch_y = a.stride[1];')
-  w('  const int x0 = strip * %d + (lane - %d) * %d;' %
-    (strip_cells, lanes_lo, V))
-  # chunk length is a launch-time value (kernel descriptor tile / waves): the
-  # host sizes it so the grid fills the GPU in whole rounds of waves
-  w('  const int chunk_len = a.tile[%d] / %d;' %
-    (ax, cfg.waves_y if dim == 2 else 1))
-  w('  const int m_begin = chunk * chunk_len;')
-  w('  const int m_end = min(m_begin + chunk_len, nm);')
-  w('  if (m_begin >= nm || strip * %d >= n0) return;  // wave-uniform' %
-    strip_cells)
-  w('  const bool lane_ok = x0 >= 0 && x0 + %d <= n0;' % V)
-  w('  const bool store_ok = lane_ok && lane >= %d && lane < %d;' %
-    (lanes_lo, 64 - lanes_hi))
-  w('  const int64_t pitch = a.stride[%d];' % ax)
-  w('  const int64_t x0c = lane_ok ? (int64_t)x0 : 0;')
-  buf = cfg.buffer_ops
-  table0 = st.symbol_table
-  esz = {nme: table0[nme].size_in_bytes for nme in list(inputs) + list(outputs)}
-  n_edge = max(edge)
-  if buf:
-    # every tensor is addressed through a window that starts at the first
-    # plane this wave touches; see soda_rt.h for the offset encoding
-    w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
-      % m_hi)
-    w('  const int wlo = max(0, m_begin + (%d));' % m_lo)
-    for es in sorted(set(esz.values())):
-      w('  const unsigned xb%d = lane_ok ? (unsigned)x0 * %du : SODA_OOB_X;' %
-        (es, es))
-      w('  const unsigned sxb%d = store_ok ? (unsigned)x0 * %du : SODA_OOB_X;' %
-        (es, es))
-      w('  const unsigned pitch_b%d = (unsigned)pitch * %du;' % (es, es))
-      if dim == 3:
-        w('  const unsigned pitch_yb%d = (unsigned)pitch_y * %du;' % (es, es))
-    for nme, n in inputs.items():
-      w('  const soda_rsrc_t r_%s = soda_make_rsrc((const %s*)a.buf[%d] + '
-        '(int64_t)wlo * pitch, (int64_t)(in_end - wlo) * pitch * %d);' %
-        (nme, n.ctype, mod.slot[nme], esz[nme]))
-    for o, n in outputs.items():
-      w('  const soda_rsrc_t w_%s = soda_make_rsrc((%s*)a.buf[%d] + '
-        '(int64_t)m_begin * pitch, (int64_t)(m_end - m_begin) * pitch * %d);' %
-        (o, n.ctype, mod.slot[o], esz[o]))
-  else:
-    for nme, n in inputs.items():
-      w('  const %s* __restrict__ p_%s = (const %s*)a.buf[%d] + x0c;' %
-        (n.ctype, nme, n.ctype, mod.slot[nme]))
-    for o, n in outputs.items():
-      w('  %s* __restrict__ q_%s = (%s*)a.buf[%d] + x0c;' %
-        (n.ctype, o, n.ctype, mod.slot[o]))
-  if n_edge:
-    # lane 0 fetches the cells left of the strip, lane 63 those right of it;
-    # DPP hands them to the shifted reads through the `old` operand
-    w('  const bool edge_lane = lane == 0 || lane == 63;')
-    for i in range(n_edge):
-      w('  const int ex%d = lane == 0 ? x0 - %d : x0 + %d;' %
-        (i, 1 + i, V + i))
-      w('  const bool edge_ok%d = edge_lane && ex%d >= 0 && ex%d < n0;' %
-        (i, i, i))
-      if buf:
-        for es in sorted({esz[nme] for nme in inputs}):
-          w('  const unsigned exb%d_%d = edge_ok%d ? (unsigned)ex%d * %du : '
-            'SODA_OOB_X;' % (i, es, i, i, es))
-      else:
-        w('  const int64_t eoff%d = edge_ok%d ? (int64_t)(ex%d - x0c) : 0;' %
-          (i, i, i))
-
-  use_bperm = cfg.lane_shift == 'bperm'
-  if use_bperm:
-    w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
-    w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
-
-  def rows_of(n: _Node):
-    return range(n.rmargin[0], rows_in - n.rmargin[1])
-
-  for n in nodes:
-    if n.to_lds:     # written at tick t, read by the next wave at tick t + R
-      w('  __shared__ %s soda_ring_%s[%d][%d];' % (n.ctype, n.var, 2 * R,
-                                                 64 * V))
-
-  def emit_decls(wv: int) -> None:
-    for n in nodes:
-      if n.owner != wv:
-        continue
-      for s in range(n.slots):
-        for j in rows_of(n):
-          w('  %s %s_s%d_r%d[%d];' % (n.ctype, n.var, s, j, V))
-          w('  soda_zero_frag<%s, %d>(%s_s%d_r%d);' % (n.ctype, V, n.var, s, j))
-          if n.is_input and n_edge:
-            w('  %s %s_s%d_r%d_e[%d];' % (n.ctype, n.var, s, j, n_edge))
-            w('  soda_zero_frag<%s, %d>(%s_s%d_r%d_e);' %
-              (n.ctype, n_edge, n.var, s, j))
-
-  if not buf:
-    w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
-      % m_hi)
-  def slot_of(n: _Node, k: int, age: int) -> int:
-    return (k - age) % n.slots
-
-  nt_l = 'true' if cfg.nt_load else 'false'
-  nt_s = 'true' if cfg.nt_store else 'false'
-
-  def emit_loads(k: int, t_expr: str) -> None:
-    """Issues the loads of input plane t (tick phase k)."""
-    w('      const int t = %s;' % t_expr)
-    w('      const bool plane_ok = t >= 0 && t < in_end;')
-    if buf:
-      in_es = sorted({esz[nme] for nme in inputs})
-      for es in in_es:
-        if dim == 2:
-          w('      const unsigned ro%d = plane_ok ? (unsigned)(t - wlo) * '
-            'pitch_b%d : SODA_OOB_ROW;' % (es, es))
-        else:
-          for j in sorted({j for n in inputs.values() for j in rows_of(n)}):
-            w('      const unsigned ro%d_%d = (plane_ok && y0 + %d >= 0 && '
-              'y0 + %d < n1) ? (unsigned)(t - wlo) * pitch_b%d + '
-              '(unsigned)(y0 + %d) * pitch_yb%d : SODA_OOB_ROW;' %
-              (es, j, j, j, es, j, es))
-    for nme, n in inputs.items():
-      s = slot_of(n, k, 0)
-      for j in (rows_of(n) if buf else []):
-        es = esz[nme]
-        ro = 'ro%d' % es if dim == 2 else 'ro%d_%d' % (es, j)
-        reg = '%s_s%d_r%d' % (n.var, s, j)
-        w('      soda_buf_load_frag<%s, %d, %s>(%s, r_%s, %s + xb%d);' %
-          (n.ctype, V, nt_l, reg, nme, ro, es))
-        for i in range(n_edge):
-          w('      { %s e1[1]; soda_buf_load_frag<%s, 1, false>(e1, r_%s, %s + '
-            'exb%d_%d); %s_e[%d] = e1[0]; }' %
-            (n.ctype, n.ctype, nme, ro, i, es, reg, i))
-      for j in ([] if buf else rows_of(n)):
-        if dim == 3:
-          cond = 'plane_ok && y0 + %d >= 0 && y0 + %d < n1' % (j, j)
-          addr = 'p_%s + (int64_t)t * pitch + (int64_t)(y0 + %d) * pitch_y' % (
-              nme, j)
-        else:
-          cond = 'plane_ok'
-          addr = 'p_%s + (int64_t)t * pitch' % nme
-        reg = '%s_s%d_r%d' % (n.var, s, j)
-        w('      if (lane_ok && %s) soda_load_frag<%s, %d, %s>(%s, %s);' %
-          (cond, n.ctype, V, nt_l, reg, addr))
-        w('      else soda_zero_frag<%s, %d>(%s);' % (n.ctype, V, reg))
-        for i in range(n_edge):
-          w('      %s_e[%d] = (edge_ok%d && %s) ? (%s)[eoff%d] : (%s)0;' %
-            (reg, i, i, cond, addr, i, n.ctype))
-
-  # The first `lead` ticks of a chunk only fill the prefetch queue: nothing a
-  # stage could compute then reaches an output plane (every stage lags its
-  # inputs by at least the prefetch depth), so they are peeled into a load-only
-  # prologue whose slot phases continue into tick 0 of the loop.
-  shift_temps = 0    # lane-shifted copies alive within one tick
-  for wv in range(W):
-   if W > 1:
-     w('  if (wave == %d) {  // iterations %d..%d of the chain' %
-       (wv, wv * (T // W), (wv + 1) * (T // W) - 1))
-   emit_decls(wv)
-   w('  int tau = m_begin + (%d);' % (m_lo + lead))
-   if wv == 0:
-     for i in range(lead):
-       w('    {  // prologue: loads of plane tau - %d' % (lead - i))
-       emit_loads((i - lead) % U, 'tau - %d' % (lead - i))
-       w('    }')
-   w('  const int tau_end = m_end + %d;' % max_delay)
-   w('  for (; tau < tau_end; tau += %d) {' % U)
-   for k in range(U):
-    w('    {  // tick %d of %d' % (k, U))
-    if W > 1 and k % R == 0:
-      w('      soda_pipe_barrier();')
-    if wv == 0:
-      emit_loads(k, 'tau + %d' % k)
-    else:
-      w('      const int t = tau + %d;' % k)
-    for n in nodes:
-      if n.mirror_of is not None and n.owner == wv:
-        # the plane the previous wave wrote R ticks (one barrier) ago
-        w('      soda_load_frag<%s, %d, false>(%s_s%d_r0, &soda_ring_%s'
-          '[(t + %d) & %d][lane * %d]);' %
-          (n.ctype, V, n.var, slot_of(n, k, 0), n.mirror_of.var, R, 2 * R - 1,
-           V))
-    # 2. compute every tensor's new plane
-    shifted: Dict[Tuple[str, int, int, int, int], str] = {}
-    stage_mark = len(L)
-    for n in nodes:
-      if n.stage is None or n.owner != wv:
-        continue
-      stage = n.stage
-      pre: List[str] = []
-      guard = None
-      if cfg.warm_guards and back_lo[id(n)] is not None:
-        first = back_lo[id(n)] + n.delay   # tick offset from m_begin
-        if first > m_lo:                   # the loop starts at m_begin + m_lo
-          guard = 't >= m_begin + (%d)' % first
-          shifted = {}                     # temporaries live inside the guard
-
-      early: List[str] = []
-
-      def operand(pname: str, off: Tuple[int, ...], j: int, e: int, _n=n,
-                  _k=k, _pre=pre, _early=early) -> str:
-        p = _n.parents[pname]
-        age = _n.delay - off[ax] - p.fill_delay
-        slot = slot_of(p, _k, age)
-        row = j + (off[1] if dim == 3 else 0)
-        if row < p.rmargin[0] or row >= rows_in - p.rmargin[1]:
-          raise util.InternalError('march: row %d of %s is not held' %
-                                   (row, p.var))
-        reg = '%s_s%d_r%d' % (p.var, slot, row)
-        c = e + off[0]
-        lane_off, sub = c // V, c % V
-        src = '%s[%d]' % (reg, sub)
-        if lane_off == 0:
-          return src
-        if cfg.lane_shift == 'none':
-          return src       # TIMING EXPERIMENTS ONLY: wrong results
-        key = (p.var, slot, row, sub, lane_off)
-        if key not in shifted:
-          tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',
-                                    abs(lane_off))
-          if p.is_input and n_edge:
-            if abs(lane_off) != 1:
-              raise util.InternalError('march: edge loads reach one lane')
-            # cell index relative to the strip end, served by the edge lane
-            ei = (-c - 1) if lane_off < 0 else (c - V)
-            old = '%s_e[%d]' % (reg, ei) if 0 <= ei < n_edge else '(%s)0' % p.ctype
-            expr = ('soda_lane_dn_or(%s, %s)' if lane_off < 0 else
-                    'soda_lane_up_or(%s, %s)') % (src, old)
-          elif use_bperm:
-            expr = src
-            for _ in range(abs(lane_off)):
-              expr = 'soda_lane_from(%s, %s)' % (
-                  'lane_dn_addr' if lane_off < 0 else 'lane_up_addr', expr)
-          else:
-            expr = src
-            for _ in range(abs(lane_off)):
-              expr = ('soda_lane_dn(%s)' if lane_off < 0 else
-                      'soda_lane_up(%s)') % expr
-          line = '      const %s %s = %s;' % (p.ctype, tmp, expr)
-          # a shift of a row produced in an EARLIER tick can be issued ahead
-          # of the previous stage's arithmetic (latency hidden behind it)
-          early = use_bperm and (p.is_input or age > 0) and not (
-              p.is_input and n_edge)
-          (_early if early else _pre).append(line)
-          shifted[key] = tmp
-        return shifted[key]
-
-      body: List[str] = []
-      dst_slot = slot_of(n, k, 0)
-      if cfg.interleave and not stage.stmt.let:
-        # all cells of the row tile at once, operation-major
-        cells = [(j, e) for j in rows_of(n) for e in range(V)]
-
-        def mk_load(j, e, _stage=stage):
-          def load(ref: ir.Ref) -> str:
-            off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
-            return operand(ref.name, off, j, e)
-          return load
-
-        counter = [0]
-
-        def fresh(_n=n, _k=k) -> str:
-          counter[0] += 1
-          return 'v_%s_k%d_%d' % (_n.var, _k, counter[0])
-
-        stmts, results = ir.c_statements(stage.stmt.expr,
-                                         [mk_load(j, e) for j, e in cells],
-                                         fresh)
-        body.extend('      ' + x for x in stmts)
-        for (j, e), r in zip(cells, results):
-          body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
-                      (n.var, dst_slot, j, e, n.ctype, r))
-      for j in ([] if (cfg.interleave and not stage.stmt.let) else rows_of(n)):
-        for e in range(V):
-
-          def load(ref: ir.Ref, _e=e, _j=j, _stage=stage) -> str:
-            off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
-            return operand(ref.name, off, _j, _e)
-
-          dst = '%s_s%d_r%d[%d]' % (n.var, dst_slot, j, e)
-          if stage.stmt.let:
-            body.append('      {')
-            for let in stage.stmt.let:
-              body.append('        const %s %s = %s;' %
-                          (let.haoda_type.c_type, let.name,
-                           ir.c_expr(let.expr, load)))
-            body.append('        %s = (%s)(%s);' %
-                        (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
-            body.append('      }')
-          else:
-            body.append('      %s = (%s)(%s);' %
-                        (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
-      if guard:
-        w('      if (%s) {  // wave-uniform' % guard)
-        L.extend(early)
-      elif early:
-        # place them in front of the previous stage's block of this tick
-        L[stage_mark:stage_mark] = early
-      stage_mark = len(L)
-      L.extend(pre)
-      L.extend(body)
-      if guard:
-        w('      }')
-        shifted = {}
-      if n.to_lds:   # hand the new plane to the next wave of the block
-        w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][lane * '
-          '%d], %s_s%d_r0);' % (n.ctype, V, n.var, 2 * R - 1, V, n.var,
-                                dst_slot))
-      # 3. store the outputs of the last iteration
-      if n.store_slot is not None:
-        oname = stage.name
-        if buf:
-          es = esz[oname]
-          w('      {')
-          w('        const int m = t - %d;' % n.delay)
-          w('        const bool m_ok = m >= m_begin && m < m_end;')
-          for j in range(max(n.rmargin[0], rhalo_lo),
-                         rows_in - max(n.rmargin[1], rhalo_hi)):
-            reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
-            if dim == 3:
-              w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
-                '< n1) ? (unsigned)(m - m_begin) * pitch_b%d + (unsigned)(y0 + '
-                '%d) * pitch_yb%d : SODA_OOB_ROW) + sxb%d, %s);' %
-                (n.ctype, V, nt_s, oname, j, es, j, es, es, reg))
-            else:
-              w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? '
-                '(unsigned)(m - m_begin) * pitch_b%d : SODA_OOB_ROW) + sxb%d, '
-                '%s);' % (n.ctype, V, nt_s, oname, es, es, reg))
-          w('      }')
-          continue
-        w('      {')
-        w('        const int m = t - %d;' % n.delay)
-        w('        if (store_ok && m >= m_begin && m < m_end) {')
-        for j in range(max(n.rmargin[0], rhalo_lo),
-                       rows_in - max(n.rmargin[1], rhalo_hi)):
-          reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
-          if dim == 3:
-            w('          if (y0 + %d < n1) soda_store_frag<%s, %d, %s>(q_%s + '
-              '(int64_t)m * pitch + (int64_t)(y0 + %d) * pitch_y, %s);' %
-              (j, n.ctype, V, nt_s, oname, j, reg))
-          else:
-            w('          soda_store_frag<%s, %d, %s>(q_%s + (int64_t)m * pitch, '
-              '%s);' % (n.ctype, V, nt_s, oname, reg))
-        w('        }')
-        w('      }')
-    shift_temps = max(shift_temps, len(shifted))
-    w('    }')
-   w('  }')
-   if W > 1:
-     w('  }')
-  w('}')
-
-  if shift_temps > MAX_SHIFT_TEMPS:
-    raise util.SemanticError(
-        'march: %d lane-shifted operands per row step (> %d); the taps reach '
-        'too far along dim 0 for %d cells per lane' %
-        (shift_temps, MAX_SHIFT_TEMPS, V))
-  est_regs += shift_temps
-  if dim == 2:
-    tile = (strip_cells * wx, cfg.chunk_rows * cfg.waves_y)
-  else:
-    tile = (strip_cells, tile_rows, cfg.chunk_rows)
-  lds_pad = 0
-  if cfg.occupancy:
-    blocks_per_cu = max(1, 4 * cfg.occupancy // waves)
-    # smallest allocation of which blocks_per_cu + 1 no longer fit
-    lds_pad = min(65536, (LDS_PER_CU // (blocks_per_cu + 1)) // 1024 * 1024
-                  + 1024)
-  idx = mod.add_kernel(
-      KernelDesc(name, (block, 1, 1), tile, lds_bytes=lds_pad,
-                 note='%s %s' % (kind, cfg.key()),
-                 tune=dict(axis=ax, waves_along=cfg.waves_y if dim == 2 else 1,
-                           waves_per_block=waves, warm=warm,
-                           fixed=cfg.chunk_fixed, occupancy=cfg.occupancy,
-                           pipe=W,
-                           window_extra=(m_hi - m_lo) if buf else None,
-                           max_elem=max(esz.values()))),
-      '\n'.join(L) + '\n')
-  table = st.symbol_table
-  bytes_in = sum(table[i].size_in_bytes for i in st.input_names)
-  bytes_out = sum(table[o].size_in_bytes for o in st.output_names)
-  redundancy = (64.0 / strip_lanes) * (
-      (cfg.chunk_rows + warm) / float(cfg.chunk_rows)) * (
-          rows_in / float(tile_rows))
-  p = PassDesc(
-      T, [idx], kind,
-      dict(bytes_per_cell_min=bytes_in + bytes_out,
-           read_redundancy=redundancy, strip_cells=strip_cells, warm_rows=warm,
-           unroll=U, edge=edge, rows_in=rows_in, tile_rows=tile_rows,
-           est_window_regs=est_regs))
-  mod.passes.append(p)
-  return p
-
-
-add_march2d_pass = add_march_pass
-
-
-# ---------------------------------------------------------------------------
-# lds2d: the classic LDS halo tile (kept as the measured alternative)
-# ---------------------------------------------------------------------------
-
-LDS2D_TILE_ROWS = 32
-
-
-def lds2d_supported(stencil: core.Stencil) -> Optional[str]:
-  if stencil.dim != 2:
-    return 'lds2d needs a 2-dimensional program'
-  if len(stencil.ordered_stages) != 1 or len(stencil.input_names) != 1:
-    return 'lds2d handles single-stage, single-input programs'
-  if stencil.ordered_stages[0].stmt.let:
-    return 'lds2d does not handle let variables'
-  return None
-
-
-def add_lds2d_pass(mod: Module, tile_rows: int = LDS2D_TILE_ROWS,
-                   nt_load: bool = True) -> PassDesc:
-  """One iteration per launch, the textbook way: a 256-thread block stages a
-  (tile_rows + halo) x (256 + halo) input tile in LDS with coalesced 16-byte
-  loads, synchronises, and every thread computes 4 consecutive cells per row
-  from LDS.  The north star names this design; it is generated so that the
-  choice between it and the register-marching kernel is a MEASUREMENT
-  (tools/sweep.py --strategy lds; profiles/r01_sweeps.md), not an assertion."""
-  st = mod.stencil
-  why = lds2d_supported(st)
-  if why:
-    raise util.SemanticError('lds2d: %s' % why)
-  stage = st.ordered_stages[0]
-  iname = st.input_names[0]
-  tlo, thi = stage.tap_bounds(iname)
-  rxl, rxh = max(0, -tlo[0]), max(0, thi[0])
-  ryl, ryh = max(0, -tlo[1]), max(0, thi[1])
-  if max(rxl, rxh) > 4:
-    raise util.SemanticError('lds2d: x radius above 4')
-  table = st.symbol_table
-  ct_in, ct_out = table[iname].c_type, stage.haoda_type.c_type
-  V = 4
-  width = 64 * V
-  pitch = width + 8                       # 4 halo cells each side, 16-B aligned
-  rows = tile_rows + ryl + ryh
-  name = '%s_lds2d_T1_R%d%s' % (st.app_name, tile_rows, '_ntl' if nt_load else '')
-  L: List[str] = []
-  w = L.append
-  w('// lds2d: %dx%d output tile per 256-thread block, %d x %d cells staged in'
-    ' LDS' % (width, tile_rows, rows, pitch))
-  w('extern "C" __global__ void __launch_bounds__(256) %s(soda_hip_kargs_t a) {'
-    % name)
-  w('  __shared__ __attribute__((aligned(16))) %s tile[%d][%d];' %
-    (ct_in, rows, pitch))
-  w('  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);')
-  w('  const unsigned nblk = gridDim.x;')
-  w('  const unsigned bid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u)'
-    ' + blockIdx.x / 8u : blockIdx.x;')
-  w('  const int x0 = (int)(bid %% (unsigned)a.ntile[0]) * %d;' % width)
-  w('  const int y0 = (int)(bid / (unsigned)a.ntile[0]) * %d;' % tile_rows)
-  w('  const int n0 = a.extent[0], n1 = a.extent[1];')
-  w('  const int64_t pitch_g = a.stride[1];')
-  w('  const %s* __restrict__ in = (const %s*)a.buf[%d];' %
-    (ct_in, ct_in, mod.slot[iname]))
-  w('  %s* __restrict__ out = (%s*)a.buf[%d];' %
-    (ct_out, ct_out, mod.slot[stage.name]))
-  w('  const int x = x0 + lane * %d;' % V)
-  w('  const bool lane_ok = x + %d <= n0;' % V)
-  # stage the tile: waves take rows round-robin
-  w('  for (int r = wave; r < %d; r += 4) {' % rows)
-  w('    const int y = y0 - %d + r;' % ryl)
-  w('    const bool row_ok = y >= 0 && y < n1;')
-  w('    %s v[%d];' % (ct_in, V))
-  w('    if (row_ok && lane_ok) soda_load_frag<%s, %d, %s>(v, in + (int64_t)y * '
-    'pitch_g + x);' % (ct_in, V, 'true' if nt_load else 'false'))
-  w('    else soda_zero_frag<%s, %d>(v);' % (ct_in, V))
-  w('    soda_store_frag<%s, %d>(&tile[r][4 + lane * %d], v);' % (ct_in, V, V))
-  if rxl or rxh:
-    w('    if (lane < %d) {  // left halo' % max(rxl, 1))
-    w('      const int hx = x0 - 1 - lane;')
-    w('      tile[r][3 - lane] = (row_ok && hx >= 0 && lane < %d) ? '
-      'in[(int64_t)y * pitch_g + hx] : (%s)0;' % (rxl, ct_in))
-    w('    } else if (lane >= 60 && lane < 60 + %d) {  // right halo' %
-      max(rxh, 1))
-    w('      const int hx = x0 + %d + (lane - 60);' % width)
-    w('      tile[r][4 + %d + (lane - 60)] = (row_ok && hx < n0) ? '
-      'in[(int64_t)y * pitch_g + hx] : (%s)0;' % (width, ct_in))
-    w('    }')
-  w('  }')
-  w('  __syncthreads();')
-  w('  for (int r = wave; r < %d; r += 4) {' % tile_rows)
-  w('    const int y = y0 + r;')
-  w('    if (y >= n1 || !lane_ok) continue;')
-  w('    %s res[%d];' % (ct_out, V))
-  for e in range(V):
-
-    def load(ref: ir.Ref, _e=e) -> str:
-      dx = ref.idx[0] - stage.st_idx[0]
-      dy = ref.idx[1] - stage.st_idx[1]
-      return 'tile[r + %d][4 + lane * %d + %d]' % (ryl + dy, V, _e + dx)
-
-    w('    res[%d] = (%s)(%s);' % (e, ct_out, ir.c_expr(stage.stmt.expr, load)))
-  w('    soda_store_frag<%s, %d>(out + (int64_t)y * pitch_g + x, res);' %
-    (ct_out, V))
-  w('  }')
-  w('}')
-  idx = mod.add_kernel(
-      KernelDesc(name, (256, 1, 1), (width, tile_rows),
-                 lds_bytes=0, note='lds2d'), '\n'.join(L) + '\n')
-  p = PassDesc(1, [idx], 'lds2d',
-               dict(bytes_per_cell_min=table[iname].size_in_bytes +
-                    stage.haoda_type.size_in_bytes,
-                    lds_bytes=rows * pitch * table[iname].size_in_bytes))
-  mod.passes.append(p)
-  return p
-
+from typing import Optional, Sequence
+
+from soda_amd import core, util
+
+from soda_amd.codegen.hip.module import (KernelDesc, Module, PassDesc,  # noqa: F401
+                                         _check_native, runtime_text)
+from soda_amd.codegen.hip.direct import DIRECT_BLOCK, add_direct_pass  # noqa: F401
+from soda_amd.codegen.hip.lds2d import (add_lds2d_pass,  # noqa: F401
+                                        lds2d_supported)
+from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_SHIFT_TEMPS,  # noqa: F401
+                                        MAX_UNROLL, REG_BUDGET, MarchConfig,
+                                        add_march_pass, default_vec,
+                                        march_supported)
 
 # ---------------------------------------------------------------------------
 # whole module
@@ -1460,3 +247,4 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
   if not use_march:
     add_direct_pass(mod, opts.vec or 1)
   return mod
+

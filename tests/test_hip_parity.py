@@ -63,7 +63,7 @@ def _check(stencil, extent, opts, iterate=None, seed=0, kind='random',
 
 
 def test_dpp_wave_shift_direction(built):
-  """soda_lane_dn/up move data the way lower.py assumes."""
+  """soda_lane_dn/up move data the way codegen/hip/march.py assumes."""
   from soda_amd import runtime
   from soda_amd.codegen.hip import lower
   src = lower.runtime_text() + '''
