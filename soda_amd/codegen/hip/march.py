@@ -257,360 +257,392 @@ def _choose_unroll(nodes: List[_Node], regs_per_plane: int,
   return None if best is None else best[1]
 
 
-def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
-  st = mod.stencil
-  why = march_supported(st)
-  if why:
-    raise util.SemanticError('march: %s' % why)
-  dim = st.dim
-  ax = dim - 1
-  T, V, PF = cfg.fused_iters, cfg.vec, cfg.prefetch
-  if T > 1 and len(st.input_names) != len(st.output_names):
-    raise util.SemanticError('march: cannot fuse iterations of a program '
-                             'whose inputs and outputs differ in number')
-  # halo cells of the program inputs that the strip's edge lanes fetch with
-  # separate narrow loads (so a 1-iteration strip keeps all 64 lanes valid and
-  # its rows start on a 64*V-cell boundary)
-  edge = (0, 0)
-  if cfg.edge_loads:
-    lo = hi = 0
-    for stage in st.ordered_stages:
-      for pname in stage.taps:
-        if pname in st.input_names:
-          tlo, thi = stage.tap_bounds(pname)
-          lo, hi = max(lo, -tlo[0]), max(hi, thi[0])
-    if max(lo, hi) <= min(V, 2):
-      edge = (lo, hi)
-  W = cfg.pipe
-  if W > 1:
-    if dim != 2 or T % W or not cfg.buffer_ops or \
-        cfg.waves_x * cfg.waves_y != 1:
-      raise util.SemanticError(
-          'march: %d pipelined waves need a 2-D program, a fusion depth that '
-          'is a multiple of it, buffer addressing and one strip per block' % W)
-    edge = (0, 0)
-  R = cfg.pipe_rows if W > 1 else 1
-  if R & (R - 1):
-    raise util.SemanticError('march: rows per barrier must be a power of two')
-  nodes, inputs, outputs = _build_chain(st, T, PF, edge, W, R)
-  out_nodes = list(outputs.values())
-  margin_lo = max(0, max(n.margin[0] for n in out_nodes))
-  margin_hi = max(0, max(n.margin[1] for n in out_nodes))
-  lanes_lo = -(-margin_lo // V)
-  lanes_hi = -(-margin_hi // V)
-  if edge != (0, 0):
-    # edge loads only pay when they save a halo lane
-    plain = _build_chain(st, T, PF, (0, 0), W, R)[2]
-    p_lo = -(-max(n.margin[0] for n in plain.values()) // V)
-    p_hi = -(-max(n.margin[1] for n in plain.values()) // V)
-    if (p_lo, p_hi) == (lanes_lo, lanes_hi):
-      edge = (0, 0)
-      nodes, inputs, outputs = _build_chain(st, T, PF, edge, W, R)
-      out_nodes = list(outputs.values())
-  if lanes_lo + lanes_hi >= 32:
-    raise util.SemanticError('march: halo of %d+%d cells is too wide for a '
-                             '64-lane strip at %d cells per lane' %
-                             (margin_lo, margin_hi, V))
-  # 3-D: rows (dim 1) of a tile held in registers
-  if dim == 3:
-    rhalo_lo = max(n.rmargin[0] for n in out_nodes)
-    rhalo_hi = max(n.rmargin[1] for n in out_nodes)
-    rows_in = cfg.tile_rows + rhalo_lo + rhalo_hi
-  else:
-    rhalo_lo = rhalo_hi = 0
-    rows_in = 1
-  tile_rows = rows_in - rhalo_lo - rhalo_hi
-  U = _choose_unroll(nodes, V * rows_in, R)
-  if U is None:
-    raise util.SemanticError(
-        'march: a tensor needs a window of %d planes (> %d)' %
-        (max(n.window for n in nodes), MAX_UNROLL))
-  for n in nodes:
-    n.slots = min(d for d in range(1, U + 1) if U % d == 0 and d >= n.window)
-  est_regs = max(
-      sum(n.slots * V * max(0, rows_in - n.rmargin[0] - n.rmargin[1])
-          for n in nodes if n.owner == wv) for wv in range(W))
-  if est_regs > 400:
-    raise util.SemanticError(
-        'march: the register windows need about %d VGPRs per lane' % est_regs)
-  for o, n in outputs.items():
-    n.store_slot = mod.slot[o]
+class _MarchKernel:
+  """One marching kernel: the schedule of the T-times unrolled stage chain
+  (constructor) and its HIP text (`emit`)."""
 
-  # lowest plane of every tensor (relative to the chunk's first output plane)
-  # that some output plane of the chunk depends on: before that, computing the
-  # tensor is wasted pipeline warm-up
-  back_lo = {id(n): None for n in nodes}
-  for n in out_nodes:
-    back_lo[id(n)] = 0
-  for n in reversed(nodes):
-    if n.stage is None or back_lo[id(n)] is None:
-      continue
-    for pname, pnode in n.parents.items():
-      tlo, _ = n.stage.tap_bounds(pname)
-      cand = back_lo[id(n)] + tlo[ax]
-      if back_lo[id(pnode)] is None or cand < back_lo[id(pnode)]:
-        back_lo[id(pnode)] = cand
-
-  strip_lanes = 64 - lanes_lo - lanes_hi
-  strip_cells = strip_lanes * V
-  max_delay = max(n.delay for n in out_nodes)
-  bounds = st.window_bounds(T)
-  m_lo = min(0, min(bounds[o][0][ax] for o in st.output_names))
-  m_hi = max(0, max(bounds[o][1][ax] for o in st.output_names))
-  # load-only ticks at the head of a chunk (buffer addressing only: the peeled
-  # loads must not need branches)
-  # A stage that lags the loads by d computes, in the first `lead` <= d ticks,
-  # only planes below every plane the chunk needs; a stage without inputs
-  # (a constant) has d = 0 and forbids the peeling.
-  lead = 0
-  if cfg.buffer_ops:
-    lead = min([PF] + [n.delay for n in nodes if n.stage is not None])
-  warm = max_delay - m_lo - lead   # compute ticks before a chunk's first output
-
-  kind = 'march%dd' % dim
-  name = '%s_%s_%s' % (st.app_name, kind, cfg.key())
-  waves = cfg.waves_x * cfg.waves_y if dim == 2 else 1
-  wx = cfg.waves_x if dim == 2 else 1
-  if W > 1:
-    waves = W
-  block = 64 * waves
-  L: List[str] = []
-  w = L.append
-  w('// %s: T=%d fused iteration(s), %d cells/lane, chunks of %d along dim %d,'
-    ' prefetch %d, unroll %d' % (kind, T, V, cfg.chunk_rows, ax, PF, U))
-  w('// strip: %d lanes valid of 64 (halo %d+%d cells, edge loads %d+%d); '
-    'pipeline depth %d' % (strip_lanes, margin_lo, margin_hi, edge[0], edge[1],
-                           warm))
-  if dim == 3:
-    w('// tile: %d rows held in registers for %d output rows (halo %d+%d)' %
-      (rows_in, tile_rows, rhalo_lo, rhalo_hi))
-  for n in nodes:
-    w('//   %-24s delay %2d  window %2d (slots %2d)  margin %d/%d  rows %d/%d' %
-      (n.var, n.delay, n.window, n.slots, n.margin[0], n.margin[1],
-       n.rmargin[0], n.rmargin[1]))
-  w('extern "C" __global__ void __launch_bounds__(%d) %s%s(soda_hip_kargs_t a) {'
-    % (block, '__attribute__((amdgpu_waves_per_eu(%d, %d))) ' %
-       (cfg.min_waves, max(cfg.min_waves, 8)) if cfg.min_waves else '', name))
-  w('  const int lane = (int)(threadIdx.x & 63u);')
-  w('  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));')
-  if cfg.xcd_swizzle:
-    # blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
-    # run of tiles so halo rows/columns shared by neighbours hit one L2
-    # (speed only; any placement is correct)
-    w('  const unsigned nblk = gridDim.x;')
-    w('  const unsigned bid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u)'
-      ' + blockIdx.x / 8u : blockIdx.x;')
-  else:
-    w('  const unsigned bid = blockIdx.x;')
-  w('  const int tile_x = (int)(bid % (unsigned)a.ntile[0]);')
-  if dim == 2:
-    w('  const int tile_m = (int)(bid / (unsigned)a.ntile[0]);')
-    if W > 1:        # all waves of the block share the strip and the chunk
-      w('  const int strip = tile_x;')
-      w('  const int chunk = tile_m;')
+  def __init__(self, mod: Module, cfg: MarchConfig):
+    self.mod, self.cfg = mod, cfg
+    self.st = self.mod.stencil
+    why = march_supported(self.st)
+    if why:
+      raise util.SemanticError('march: %s' % why)
+    self.dim = self.st.dim
+    self.ax = self.dim - 1
+    self.T, self.V, self.PF = self.cfg.fused_iters, self.cfg.vec, self.cfg.prefetch
+    if self.T > 1 and len(self.st.input_names) != len(self.st.output_names):
+      raise util.SemanticError('march: cannot fuse iterations of a program '
+                               'whose inputs and outputs differ in number')
+    # halo cells of the program inputs that the strip's edge lanes fetch with
+    # separate narrow loads (so a 1-iteration strip keeps all 64 lanes valid and
+    # its rows start on a 64*V-cell boundary)
+    self.edge = (0, 0)
+    if self.cfg.edge_loads:
+      lo = hi = 0
+      for stage in self.st.ordered_stages:
+        for pname in stage.taps:
+          if pname in self.st.input_names:
+            tlo, thi = stage.tap_bounds(pname)
+            lo, hi = max(lo, -tlo[0]), max(hi, thi[0])
+      if max(lo, hi) <= min(self.V, 2):
+        self.edge = (lo, hi)
+    self.W = self.cfg.pipe
+    if self.W > 1:
+      if self.dim != 2 or self.T % self.W or not self.cfg.buffer_ops or \
+          self.cfg.waves_x * self.cfg.waves_y != 1:
+        raise util.SemanticError(
+            'march: %d pipelined waves need a 2-D program, a fusion depth that '
+            'is a multiple of it, buffer addressing and one strip per block' % self.W)
+      self.edge = (0, 0)
+    self.R = self.cfg.pipe_rows if self.W > 1 else 1
+    if self.R & (self.R - 1):
+      raise util.SemanticError('march: rows per barrier must be a power of two')
+    self.nodes, self.inputs, self.outputs = _build_chain(
+        self.st, self.T, self.PF, self.edge, self.W, self.R)
+    self.out_nodes = list(self.outputs.values())
+    self.margin_lo = max(0, max(n.margin[0] for n in self.out_nodes))
+    self.margin_hi = max(0, max(n.margin[1] for n in self.out_nodes))
+    self.lanes_lo = -(-self.margin_lo // self.V)
+    self.lanes_hi = -(-self.margin_hi // self.V)
+    if self.edge != (0, 0):
+      # edge loads only pay when they save a halo lane
+      plain = _build_chain(self.st, self.T, self.PF, (0, 0), self.W, self.R)[2]
+      p_lo = -(-max(n.margin[0] for n in plain.values()) // self.V)
+      p_hi = -(-max(n.margin[1] for n in plain.values()) // self.V)
+      if (p_lo, p_hi) == (self.lanes_lo, self.lanes_hi):
+        self.edge = (0, 0)
+        self.nodes, self.inputs, self.outputs = _build_chain(
+            self.st, self.T, self.PF, self.edge, self.W, self.R)
+        self.out_nodes = list(self.outputs.values())
+    if self.lanes_lo + self.lanes_hi >= 32:
+      raise util.SemanticError('march: halo of %d+%d cells is too wide for a '
+                               '64-lane strip at %d cells per lane' %
+                               (self.margin_lo, self.margin_hi, self.V))
+    # 3-D: rows (dim 1) of a tile held in registers
+    if self.dim == 3:
+      self.rhalo_lo = max(n.rmargin[0] for n in self.out_nodes)
+      self.rhalo_hi = max(n.rmargin[1] for n in self.out_nodes)
+      self.rows_in = self.cfg.tile_rows + self.rhalo_lo + self.rhalo_hi
     else:
-      w('  const int strip = tile_x * %d + wave %% %d;' % (wx, wx))
-      w('  const int chunk = tile_m * %d + wave / %d;' % (cfg.waves_y, wx))
-    w('  const int n0 = a.extent[0], nm = a.extent[1];')
-  else:
-    w('  const int tile_y = (int)((bid / (unsigned)a.ntile[0]) % '
-      '(unsigned)a.ntile[1]);')
-    w('  const int chunk = (int)(bid / ((unsigned)a.ntile[0] * '
-      '(unsigned)a.ntile[1]));')
-    w('  const int strip = tile_x;')
-    w('  const int n0 = a.extent[0], n1 = a.extent[1], nm = a.extent[2];')
-    w('  const int y0 = tile_y * %d - %d;  // first row held' %
-      (tile_rows, rhalo_lo))
-    w('  const int64_t pitch_y = a.stride[1];')
-  w('  const int x0 = strip * %d + (lane - %d) * %d;' %
-    (strip_cells, lanes_lo, V))
-  # chunk length is a launch-time value (kernel descriptor tile / waves): the
-  # host sizes it so the grid fills the GPU in whole rounds of waves
-  w('  const int chunk_len = a.tile[%d] / %d;' %
-    (ax, cfg.waves_y if dim == 2 else 1))
-  w('  const int m_begin = chunk * chunk_len;')
-  w('  const int m_end = min(m_begin + chunk_len, nm);')
-  w('  if (m_begin >= nm || strip * %d >= n0) return;  // wave-uniform' %
-    strip_cells)
-  w('  const bool lane_ok = x0 >= 0 && x0 + %d <= n0;' % V)
-  w('  const bool store_ok = lane_ok && lane >= %d && lane < %d;' %
-    (lanes_lo, 64 - lanes_hi))
-  w('  const int64_t pitch = a.stride[%d];' % ax)
-  w('  const int64_t x0c = lane_ok ? (int64_t)x0 : 0;')
-  buf = cfg.buffer_ops
-  table0 = st.symbol_table
-  esz = {nme: table0[nme].size_in_bytes for nme in list(inputs) + list(outputs)}
-  n_edge = max(edge)
-  if buf:
-    # every tensor is addressed through a window that starts at the first
-    # plane this wave touches; see soda_rt.h for the offset encoding
-    w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
-      % m_hi)
-    w('  const int wlo = max(0, m_begin + (%d));' % m_lo)
-    for es in sorted(set(esz.values())):
-      w('  const unsigned xb%d = lane_ok ? (unsigned)x0 * %du : SODA_OOB_X;' %
-        (es, es))
-      w('  const unsigned sxb%d = store_ok ? (unsigned)x0 * %du : SODA_OOB_X;' %
-        (es, es))
-      w('  const unsigned pitch_b%d = (unsigned)pitch * %du;' % (es, es))
-      if dim == 3:
-        w('  const unsigned pitch_yb%d = (unsigned)pitch_y * %du;' % (es, es))
-    for nme, n in inputs.items():
-      w('  const soda_rsrc_t r_%s = soda_make_rsrc((const %s*)a.buf[%d] + '
-        '(int64_t)wlo * pitch, (int64_t)(in_end - wlo) * pitch * %d);' %
-        (nme, n.ctype, mod.slot[nme], esz[nme]))
-    for o, n in outputs.items():
-      w('  const soda_rsrc_t w_%s = soda_make_rsrc((%s*)a.buf[%d] + '
-        '(int64_t)m_begin * pitch, (int64_t)(m_end - m_begin) * pitch * %d);' %
-        (o, n.ctype, mod.slot[o], esz[o]))
-  else:
-    for nme, n in inputs.items():
-      w('  const %s* __restrict__ p_%s = (const %s*)a.buf[%d] + x0c;' %
-        (n.ctype, nme, n.ctype, mod.slot[nme]))
-    for o, n in outputs.items():
-      w('  %s* __restrict__ q_%s = (%s*)a.buf[%d] + x0c;' %
-        (n.ctype, o, n.ctype, mod.slot[o]))
-  if n_edge:
-    # lane 0 fetches the cells left of the strip, lane 63 those right of it;
-    # DPP hands them to the shifted reads through the `old` operand
-    w('  const bool edge_lane = lane == 0 || lane == 63;')
-    for i in range(n_edge):
-      w('  const int ex%d = lane == 0 ? x0 - %d : x0 + %d;' %
-        (i, 1 + i, V + i))
-      w('  const bool edge_ok%d = edge_lane && ex%d >= 0 && ex%d < n0;' %
-        (i, i, i))
-      if buf:
-        for es in sorted({esz[nme] for nme in inputs}):
-          w('  const unsigned exb%d_%d = edge_ok%d ? (unsigned)ex%d * %du : '
-            'SODA_OOB_X;' % (i, es, i, i, es))
-      else:
-        w('  const int64_t eoff%d = edge_ok%d ? (int64_t)(ex%d - x0c) : 0;' %
-          (i, i, i))
+      self.rhalo_lo = self.rhalo_hi = 0
+      self.rows_in = 1
+    self.tile_rows = self.rows_in - self.rhalo_lo - self.rhalo_hi
+    self.U = _choose_unroll(self.nodes, self.V * self.rows_in, self.R)
+    if self.U is None:
+      raise util.SemanticError(
+          'march: a tensor needs a window of %d planes (> %d)' %
+          (max(n.window for n in self.nodes), MAX_UNROLL))
+    for n in self.nodes:
+      n.slots = min(d for d in range(1, self.U + 1) if self.U % d == 0 and d >= n.window)
+    self.est_regs = max(
+        sum(n.slots * self.V * max(0, self.rows_in - n.rmargin[0] - n.rmargin[1])
+            for n in self.nodes if n.owner == wv) for wv in range(self.W))
+    if self.est_regs > 400:
+      raise util.SemanticError(
+          'march: the register windows need about %d VGPRs per lane' % self.est_regs)
+    for o, n in self.outputs.items():
+      n.store_slot = self.mod.slot[o]
 
-  use_bperm = cfg.lane_shift == 'bperm'
-  if use_bperm:
-    w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
-    w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
-
-  def rows_of(n: _Node):
-    return range(n.rmargin[0], rows_in - n.rmargin[1])
-
-  for n in nodes:
-    if n.to_lds:     # written at tick t, read by the next wave at tick t + R
-      w('  __shared__ %s soda_ring_%s[%d][%d];' % (n.ctype, n.var, 2 * R,
-                                                 64 * V))
-
-  def emit_decls(wv: int) -> None:
-    for n in nodes:
-      if n.owner != wv:
+    # lowest plane of every tensor (relative to the chunk's first output plane)
+    # that some output plane of the chunk depends on: before that, computing the
+    # tensor is wasted pipeline warm-up
+    self.back_lo = {id(n): None for n in self.nodes}
+    for n in self.out_nodes:
+      self.back_lo[id(n)] = 0
+    for n in reversed(self.nodes):
+      if n.stage is None or self.back_lo[id(n)] is None:
         continue
-      for s in range(n.slots):
-        for j in rows_of(n):
-          w('  %s %s_s%d_r%d[%d];' % (n.ctype, n.var, s, j, V))
-          w('  soda_zero_frag<%s, %d>(%s_s%d_r%d);' % (n.ctype, V, n.var, s, j))
-          if n.is_input and n_edge:
-            w('  %s %s_s%d_r%d_e[%d];' % (n.ctype, n.var, s, j, n_edge))
-            w('  soda_zero_frag<%s, %d>(%s_s%d_r%d_e);' %
-              (n.ctype, n_edge, n.var, s, j))
+      for pname, pnode in n.parents.items():
+        tlo, _ = n.stage.tap_bounds(pname)
+        cand = self.back_lo[id(n)] + tlo[self.ax]
+        if self.back_lo[id(pnode)] is None or cand < self.back_lo[id(pnode)]:
+          self.back_lo[id(pnode)] = cand
 
-  if not buf:
-    w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
-      % m_hi)
+    self.strip_lanes = 64 - self.lanes_lo - self.lanes_hi
+    self.strip_cells = self.strip_lanes * self.V
+    self.max_delay = max(n.delay for n in self.out_nodes)
+    bounds = self.st.window_bounds(self.T)
+    self.m_lo = min(0, min(bounds[o][0][self.ax] for o in self.st.output_names))
+    self.m_hi = max(0, max(bounds[o][1][self.ax] for o in self.st.output_names))
+    # load-only ticks at the head of a chunk (buffer addressing only: the peeled
+    # loads must not need branches)
+    # A stage that lags the loads by d computes, in the first `lead` <= d ticks,
+    # only planes below every plane the chunk needs; a stage without inputs
+    # (a constant) has d = 0 and forbids the peeling.
+    self.lead = 0
+    if self.cfg.buffer_ops:
+      self.lead = min([self.PF] + [n.delay for n in self.nodes if n.stage is not None])
+    # compute ticks before a chunk's first output
+    self.warm = self.max_delay - self.m_lo - self.lead
+
+    self.kind = 'march%dd' % self.dim
+    self.name = '%s_%s_%s' % (self.st.app_name, self.kind, self.cfg.key())
+    self.waves = self.cfg.waves_x * self.cfg.waves_y if self.dim == 2 else 1
+    self.wx = self.cfg.waves_x if self.dim == 2 else 1
+    if self.W > 1:
+      self.waves = self.W
+    self.block = 64 * self.waves
+    self.L: List[str] = []
+    self.w = self.L.append
+    self.shift_temps = 0    # lane-shifted copies alive within one tick
+
+  def rows_of(self, n: _Node):
+    return range(n.rmargin[0], self.rows_in - n.rmargin[1])
+
+  @staticmethod
   def slot_of(n: _Node, k: int, age: int) -> int:
     return (k - age) % n.slots
 
-  nt_l = 'true' if cfg.nt_load else 'false'
-  nt_s = 'true' if cfg.nt_store else 'false'
+  # -- emission ---------------------------------------------------------------
+  def emit(self) -> PassDesc:
+    self._emit_header()
+    self._emit_addressing()
+    for wv in range(self.W):
+      self._emit_wave(wv)
+    self.w('}')
+    return self._finish()
 
-  def emit_loads(k: int, t_expr: str) -> None:
-    """Issues the loads of input plane t (tick phase k)."""
-    w('      const int t = %s;' % t_expr)
-    w('      const bool plane_ok = t >= 0 && t < in_end;')
-    if buf:
-      in_es = sorted({esz[nme] for nme in inputs})
-      for es in in_es:
-        if dim == 2:
-          w('      const unsigned ro%d = plane_ok ? (unsigned)(t - wlo) * '
-            'pitch_b%d : SODA_OOB_ROW;' % (es, es))
-        else:
-          for j in sorted({j for n in inputs.values() for j in rows_of(n)}):
-            w('      const unsigned ro%d_%d = (plane_ok && y0 + %d >= 0 && '
-              'y0 + %d < n1) ? (unsigned)(t - wlo) * pitch_b%d + '
-              '(unsigned)(y0 + %d) * pitch_yb%d : SODA_OOB_ROW;' %
-              (es, j, j, j, es, j, es))
-    for nme, n in inputs.items():
-      s = slot_of(n, k, 0)
-      for j in (rows_of(n) if buf else []):
-        es = esz[nme]
-        ro = 'ro%d' % es if dim == 2 else 'ro%d_%d' % (es, j)
-        reg = '%s_s%d_r%d' % (n.var, s, j)
-        w('      soda_buf_load_frag<%s, %d, %s>(%s, r_%s, %s + xb%d);' %
-          (n.ctype, V, nt_l, reg, nme, ro, es))
-        for i in range(n_edge):
-          w('      { %s e1[1]; soda_buf_load_frag<%s, 1, false>(e1, r_%s, %s + '
-            'exb%d_%d); %s_e[%d] = e1[0]; }' %
-            (n.ctype, n.ctype, nme, ro, i, es, reg, i))
-      for j in ([] if buf else rows_of(n)):
-        if dim == 3:
-          cond = 'plane_ok && y0 + %d >= 0 && y0 + %d < n1' % (j, j)
-          addr = 'p_%s + (int64_t)t * pitch + (int64_t)(y0 + %d) * pitch_y' % (
-              nme, j)
-        else:
-          cond = 'plane_ok'
-          addr = 'p_%s + (int64_t)t * pitch' % nme
-        reg = '%s_s%d_r%d' % (n.var, s, j)
-        w('      if (lane_ok && %s) soda_load_frag<%s, %d, %s>(%s, %s);' %
-          (cond, n.ctype, V, nt_l, reg, addr))
-        w('      else soda_zero_frag<%s, %d>(%s);' % (n.ctype, V, reg))
-        for i in range(n_edge):
-          w('      %s_e[%d] = (edge_ok%d && %s) ? (%s)[eoff%d] : (%s)0;' %
-            (reg, i, i, cond, addr, i, n.ctype))
-
-  # The first `lead` ticks of a chunk only fill the prefetch queue: nothing a
-  # stage could compute then reaches an output plane (every stage lags its
-  # inputs by at least the prefetch depth), so they are peeled into a load-only
-  # prologue whose slot phases continue into tick 0 of the loop.
-  shift_temps = 0    # lane-shifted copies alive within one tick
-  for wv in range(W):
-   if W > 1:
-     w('  if (wave == %d) {  // iterations %d..%d of the chain' %
-       (wv, wv * (T // W), (wv + 1) * (T // W) - 1))
-   emit_decls(wv)
-   w('  int tau = m_begin + (%d);' % (m_lo + lead))
-   if wv == 0:
-     for i in range(lead):
-       w('    {  // prologue: loads of plane tau - %d' % (lead - i))
-       emit_loads((i - lead) % U, 'tau - %d' % (lead - i))
-       w('    }')
-   w('  const int tau_end = m_end + %d;' % max_delay)
-   w('  for (; tau < tau_end; tau += %d) {' % U)
-   for k in range(U):
-    w('    {  // tick %d of %d' % (k, U))
-    if W > 1 and k % R == 0:
-      w('      soda_pipe_barrier();')
-    if wv == 0:
-      emit_loads(k, 'tau + %d' % k)
+  def _emit_header(self) -> None:
+    self.w('// %s: T=%d fused iteration(s), %d cells/lane, chunks of %d along dim %d,'
+      ' prefetch %d, unroll %d' % (self.kind, self.T, self.V,
+                                   self.cfg.chunk_rows, self.ax, self.PF,
+                                   self.U))
+    self.w('// strip: %d lanes valid of 64 (halo %d+%d cells, edge loads %d+%d); '
+      'pipeline depth %d' % (self.strip_lanes, self.margin_lo, self.margin_hi,
+                             self.edge[0], self.edge[1],
+                             self.warm))
+    if self.dim == 3:
+      self.w('// tile: %d rows held in registers for %d output rows (halo %d+%d)' %
+        (self.rows_in, self.tile_rows, self.rhalo_lo, self.rhalo_hi))
+    for n in self.nodes:
+      self.w('//   %-24s delay %2d  window %2d (slots %2d)  margin %d/%d  rows %d/%d' %
+        (n.var, n.delay, n.window, n.slots, n.margin[0], n.margin[1],
+         n.rmargin[0], n.rmargin[1]))
+    self.w('extern "C" __global__ void __launch_bounds__(%d) %s%s(soda_hip_kargs_t a) {'
+      % (self.block, '__attribute__((amdgpu_waves_per_eu(%d, %d))) ' %
+         (self.cfg.min_waves, max(self.cfg.min_waves, 8))
+         if self.cfg.min_waves else '', self.name))
+    self.w('  const int lane = (int)(threadIdx.x & 63u);')
+    self.w('  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));')
+    if self.cfg.xcd_swizzle:
+      # blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
+      # run of tiles so halo rows/columns shared by neighbours hit one L2
+      # (speed only; any placement is correct)
+      self.w('  const unsigned nblk = gridDim.x;')
+      self.w('  const unsigned bid = (nblk % 8u == 0u) ? (blockIdx.x % 8u) * (nblk / 8u)'
+        ' + blockIdx.x / 8u : blockIdx.x;')
     else:
-      w('      const int t = tau + %d;' % k)
-    for n in nodes:
+      self.w('  const unsigned bid = blockIdx.x;')
+    self.w('  const int tile_x = (int)(bid % (unsigned)a.ntile[0]);')
+    if self.dim == 2:
+      self.w('  const int tile_m = (int)(bid / (unsigned)a.ntile[0]);')
+      if self.W > 1:        # all waves of the block share the strip and the chunk
+        self.w('  const int strip = tile_x;')
+        self.w('  const int chunk = tile_m;')
+      else:
+        self.w('  const int strip = tile_x * %d + wave %% %d;' % (self.wx, self.wx))
+        self.w('  const int chunk = tile_m * %d + wave / %d;' % (self.cfg.waves_y, self.wx))
+      self.w('  const int n0 = a.extent[0], nm = a.extent[1];')
+    else:
+      self.w('  const int tile_y = (int)((bid / (unsigned)a.ntile[0]) % '
+        '(unsigned)a.ntile[1]);')
+      self.w('  const int chunk = (int)(bid / ((unsigned)a.ntile[0] * '
+        '(unsigned)a.ntile[1]));')
+      self.w('  const int strip = tile_x;')
+      self.w('  const int n0 = a.extent[0], n1 = a.extent[1], nm = a.extent[2];')
+      self.w('  const int y0 = tile_y * %d - %d;  // first row held' %
+        (self.tile_rows, self.rhalo_lo))
+      self.w('  const int64_t pitch_y = a.stride[1];')
+    self.w('  const int x0 = strip * %d + (lane - %d) * %d;' %
+      (self.strip_cells, self.lanes_lo, self.V))
+    # chunk length is a launch-time value (kernel descriptor tile / waves): the
+    # host sizes it so the grid fills the GPU in whole rounds of waves
+    self.w('  const int chunk_len = a.tile[%d] / %d;' %
+      (self.ax, self.cfg.waves_y if self.dim == 2 else 1))
+    self.w('  const int m_begin = chunk * chunk_len;')
+    self.w('  const int m_end = min(m_begin + chunk_len, nm);')
+    self.w('  if (m_begin >= nm || strip * %d >= n0) return;  // wave-uniform' %
+      self.strip_cells)
+    self.w('  const bool lane_ok = x0 >= 0 && x0 + %d <= n0;' % self.V)
+    self.w('  const bool store_ok = lane_ok && lane >= %d && lane < %d;' %
+      (self.lanes_lo, 64 - self.lanes_hi))
+    self.w('  const int64_t pitch = a.stride[%d];' % self.ax)
+    self.w('  const int64_t x0c = lane_ok ? (int64_t)x0 : 0;')
+
+  def _emit_addressing(self) -> None:
+    self.buf = self.cfg.buffer_ops
+    table0 = self.st.symbol_table
+    self.esz = {nme: table0[nme].size_in_bytes for nme in list(self.inputs) + list(self.outputs)}
+    self.n_edge = max(self.edge)
+    if self.buf:
+      # every tensor is addressed through a window that starts at the first
+      # plane this wave touches; see soda_rt.h for the offset encoding
+      self.w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
+        % self.m_hi)
+      self.w('  const int wlo = max(0, m_begin + (%d));' % self.m_lo)
+      for es in sorted(set(self.esz.values())):
+        self.w('  const unsigned xb%d = lane_ok ? (unsigned)x0 * %du : SODA_OOB_X;' %
+          (es, es))
+        self.w('  const unsigned sxb%d = store_ok ? (unsigned)x0 * %du : SODA_OOB_X;' %
+          (es, es))
+        self.w('  const unsigned pitch_b%d = (unsigned)pitch * %du;' % (es, es))
+        if self.dim == 3:
+          self.w('  const unsigned pitch_yb%d = (unsigned)pitch_y * %du;' % (es, es))
+      for nme, n in self.inputs.items():
+        self.w('  const soda_rsrc_t r_%s = soda_make_rsrc((const %s*)a.buf[%d] + '
+          '(int64_t)wlo * pitch, (int64_t)(in_end - wlo) * pitch * %d);' %
+          (nme, n.ctype, self.mod.slot[nme], self.esz[nme]))
+      for o, n in self.outputs.items():
+        self.w('  const soda_rsrc_t w_%s = soda_make_rsrc((%s*)a.buf[%d] + '
+          '(int64_t)m_begin * pitch, (int64_t)(m_end - m_begin) * pitch * %d);' %
+          (o, n.ctype, self.mod.slot[o], self.esz[o]))
+    else:
+      for nme, n in self.inputs.items():
+        self.w('  const %s* __restrict__ p_%s = (const %s*)a.buf[%d] + x0c;' %
+          (n.ctype, nme, n.ctype, self.mod.slot[nme]))
+      for o, n in self.outputs.items():
+        self.w('  %s* __restrict__ q_%s = (%s*)a.buf[%d] + x0c;' %
+          (n.ctype, o, n.ctype, self.mod.slot[o]))
+    if self.n_edge:
+      # lane 0 fetches the cells left of the strip, lane 63 those right of it;
+      # DPP hands them to the shifted reads through the `old` operand
+      self.w('  const bool edge_lane = lane == 0 || lane == 63;')
+      for i in range(self.n_edge):
+        self.w('  const int ex%d = lane == 0 ? x0 - %d : x0 + %d;' %
+          (i, 1 + i, self.V + i))
+        self.w('  const bool edge_ok%d = edge_lane && ex%d >= 0 && ex%d < n0;' %
+          (i, i, i))
+        if self.buf:
+          for es in sorted({self.esz[nme] for nme in self.inputs}):
+            self.w('  const unsigned exb%d_%d = edge_ok%d ? (unsigned)ex%d * %du : '
+              'SODA_OOB_X;' % (i, es, i, i, es))
+        else:
+          self.w('  const int64_t eoff%d = edge_ok%d ? (int64_t)(ex%d - x0c) : 0;' %
+            (i, i, i))
+
+    self.use_bperm = self.cfg.lane_shift == 'bperm'
+    if self.use_bperm:
+      self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
+      self.w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
+    for n in self.nodes:
+      if n.to_lds:     # written at tick t, read by the next wave at tick t + R
+        self.w('  __shared__ %s soda_ring_%s[%d][%d];' % (n.ctype, n.var, 2 * self.R,
+                                                   64 * self.V))
+    if not self.buf:
+      self.w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
+        % self.m_hi)
+    self.nt_l = 'true' if self.cfg.nt_load else 'false'
+    self.nt_s = 'true' if self.cfg.nt_store else 'false'
+
+  def emit_decls(self, wv: int) -> None:
+      for n in self.nodes:
+        if n.owner != wv:
+          continue
+        for s in range(n.slots):
+          for j in self.rows_of(n):
+            self.w('  %s %s_s%d_r%d[%d];' % (n.ctype, n.var, s, j, self.V))
+            self.w('  soda_zero_frag<%s, %d>(%s_s%d_r%d);' % (n.ctype, self.V, n.var, s, j))
+            if n.is_input and self.n_edge:
+              self.w('  %s %s_s%d_r%d_e[%d];' % (n.ctype, n.var, s, j, self.n_edge))
+              self.w('  soda_zero_frag<%s, %d>(%s_s%d_r%d_e);' %
+                (n.ctype, self.n_edge, n.var, s, j))
+
+  def emit_loads(self, k: int, t_expr: str) -> None:
+      """Issues the loads of input plane t (tick phase k)."""
+      self.w('      const int t = %s;' % t_expr)
+      self.w('      const bool plane_ok = t >= 0 && t < in_end;')
+      if self.buf:
+        in_es = sorted({self.esz[nme] for nme in self.inputs})
+        for es in in_es:
+          if self.dim == 2:
+            self.w('      const unsigned ro%d = plane_ok ? (unsigned)(t - wlo) * '
+              'pitch_b%d : SODA_OOB_ROW;' % (es, es))
+          else:
+            for j in sorted({j for n in self.inputs.values() for j in self.rows_of(n)}):
+              self.w('      const unsigned ro%d_%d = (plane_ok && y0 + %d >= 0 && '
+                'y0 + %d < n1) ? (unsigned)(t - wlo) * pitch_b%d + '
+                '(unsigned)(y0 + %d) * pitch_yb%d : SODA_OOB_ROW;' %
+                (es, j, j, j, es, j, es))
+      for nme, n in self.inputs.items():
+        s = self.slot_of(n, k, 0)
+        for j in (self.rows_of(n) if self.buf else []):
+          es = self.esz[nme]
+          ro = 'ro%d' % es if self.dim == 2 else 'ro%d_%d' % (es, j)
+          reg = '%s_s%d_r%d' % (n.var, s, j)
+          self.w('      soda_buf_load_frag<%s, %d, %s>(%s, r_%s, %s + xb%d);' %
+            (n.ctype, self.V, self.nt_l, reg, nme, ro, es))
+          for i in range(self.n_edge):
+            self.w('      { %s e1[1]; soda_buf_load_frag<%s, 1, false>(e1, r_%s, %s + '
+              'exb%d_%d); %s_e[%d] = e1[0]; }' %
+              (n.ctype, n.ctype, nme, ro, i, es, reg, i))
+        for j in ([] if self.buf else self.rows_of(n)):
+          if self.dim == 3:
+            cond = 'plane_ok && y0 + %d >= 0 && y0 + %d < n1' % (j, j)
+            addr = 'p_%s + (int64_t)t * pitch + (int64_t)(y0 + %d) * pitch_y' % (
+                nme, j)
+          else:
+            cond = 'plane_ok'
+            addr = 'p_%s + (int64_t)t * pitch' % nme
+          reg = '%s_s%d_r%d' % (n.var, s, j)
+          self.w('      if (lane_ok && %s) soda_load_frag<%s, %d, %s>(%s, %s);' %
+            (cond, n.ctype, self.V, self.nt_l, reg, addr))
+          self.w('      else soda_zero_frag<%s, %d>(%s);' % (n.ctype, self.V, reg))
+          for i in range(self.n_edge):
+            self.w('      %s_e[%d] = (edge_ok%d && %s) ? (%s)[eoff%d] : (%s)0;' %
+              (reg, i, i, cond, addr, i, n.ctype))
+
+  def _emit_wave(self, wv: int) -> None:
+    """The tick loop of one wave of the block (the only one unless the
+    block is stage-pipelined)."""
+    if self.W > 1:
+      self.w('  if (wave == %d) {  // iterations %d..%d of the chain' %
+             (wv, wv * (self.T // self.W), (wv + 1) * (self.T // self.W) - 1))
+    self.emit_decls(wv)
+    # The first `lead` ticks of a chunk only fill the prefetch queue: nothing a
+    # stage could compute then reaches an output plane (every stage lags its
+    # inputs by at least the prefetch depth), so they are peeled into a
+    # load-only prologue whose slot phases continue into tick 0 of the loop.
+    self.w('  int tau = m_begin + (%d);' % (self.m_lo + self.lead))
+    if wv == 0:
+      for i in range(self.lead):
+        self.w('    {  // prologue: loads of plane tau - %d' % (self.lead - i))
+        self.emit_loads((i - self.lead) % self.U, 'tau - %d' % (self.lead - i))
+        self.w('    }')
+    self.w('  const int tau_end = m_end + %d;' % self.max_delay)
+    self.w('  for (; tau < tau_end; tau += %d) {' % self.U)
+    for k in range(self.U):
+      self._emit_tick(wv, k)
+    self.w('  }')
+    if self.W > 1:
+      self.w('  }')
+
+  def _emit_tick(self, wv: int, k: int) -> None:
+    self.w('    {  // tick %d of %d' % (k, self.U))
+    if self.W > 1 and k % self.R == 0:
+      self.w('      soda_pipe_barrier();')
+    if wv == 0:
+      self.emit_loads(k, 'tau + %d' % k)
+    else:
+      self.w('      const int t = tau + %d;' % k)
+    for n in self.nodes:
       if n.mirror_of is not None and n.owner == wv:
         # the plane the previous wave wrote R ticks (one barrier) ago
-        w('      soda_load_frag<%s, %d, false>(%s_s%d_r0, &soda_ring_%s'
+        self.w('      soda_load_frag<%s, %d, false>(%s_s%d_r0, &soda_ring_%s'
           '[(t + %d) & %d][lane * %d]);' %
-          (n.ctype, V, n.var, slot_of(n, k, 0), n.mirror_of.var, R, 2 * R - 1,
-           V))
+          (n.ctype, self.V, n.var, self.slot_of(n, k, 0), n.mirror_of.var, self.R, 2 * self.R - 1,
+           self.V))
     # 2. compute every tensor's new plane
     shifted: Dict[Tuple[str, int, int, int, int], str] = {}
-    stage_mark = len(L)
-    for n in nodes:
+    stage_mark = len(self.L)
+    for n in self.nodes:
       if n.stage is None or n.owner != wv:
         continue
       stage = n.stage
       pre: List[str] = []
       guard = None
-      if cfg.warm_guards and back_lo[id(n)] is not None:
-        first = back_lo[id(n)] + n.delay   # tick offset from m_begin
-        if first > m_lo:                   # the loop starts at m_begin + m_lo
+      if self.cfg.warm_guards and self.back_lo[id(n)] is not None:
+        first = self.back_lo[id(n)] + n.delay   # tick offset from m_begin
+        if first > self.m_lo:                   # the loop starts at m_begin + m_lo
           guard = 't >= m_begin + (%d)' % first
           shifted = {}                     # temporaries live inside the guard
 
@@ -619,33 +651,33 @@ def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
       def operand(pname: str, off: Tuple[int, ...], j: int, e: int, _n=n,
                   _k=k, _pre=pre, _early=early) -> str:
         p = _n.parents[pname]
-        age = _n.delay - off[ax] - p.fill_delay
-        slot = slot_of(p, _k, age)
-        row = j + (off[1] if dim == 3 else 0)
-        if row < p.rmargin[0] or row >= rows_in - p.rmargin[1]:
+        age = _n.delay - off[self.ax] - p.fill_delay
+        slot = self.slot_of(p, _k, age)
+        row = j + (off[1] if self.dim == 3 else 0)
+        if row < p.rmargin[0] or row >= self.rows_in - p.rmargin[1]:
           raise util.InternalError('march: row %d of %s is not held' %
                                    (row, p.var))
         reg = '%s_s%d_r%d' % (p.var, slot, row)
         c = e + off[0]
-        lane_off, sub = c // V, c % V
+        lane_off, sub = c // self.V, c % self.V
         src = '%s[%d]' % (reg, sub)
         if lane_off == 0:
           return src
-        if cfg.lane_shift == 'none':
+        if self.cfg.lane_shift == 'none':
           return src       # TIMING EXPERIMENTS ONLY: wrong results
         key = (p.var, slot, row, sub, lane_off)
         if key not in shifted:
           tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',
                                     abs(lane_off))
-          if p.is_input and n_edge:
+          if p.is_input and self.n_edge:
             if abs(lane_off) != 1:
               raise util.InternalError('march: edge loads reach one lane')
             # cell index relative to the strip end, served by the edge lane
-            ei = (-c - 1) if lane_off < 0 else (c - V)
-            old = '%s_e[%d]' % (reg, ei) if 0 <= ei < n_edge else '(%s)0' % p.ctype
+            ei = (-c - 1) if lane_off < 0 else (c - self.V)
+            old = '%s_e[%d]' % (reg, ei) if 0 <= ei < self.n_edge else '(%s)0' % p.ctype
             expr = ('soda_lane_dn_or(%s, %s)' if lane_off < 0 else
                     'soda_lane_up_or(%s, %s)') % (src, old)
-          elif use_bperm:
+          elif self.use_bperm:
             expr = src
             for _ in range(abs(lane_off)):
               expr = 'soda_lane_from(%s, %s)' % (
@@ -658,17 +690,17 @@ def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
           line = '      const %s %s = %s;' % (p.ctype, tmp, expr)
           # a shift of a row produced in an EARLIER tick can be issued ahead
           # of the previous stage's arithmetic (latency hidden behind it)
-          early = use_bperm and (p.is_input or age > 0) and not (
-              p.is_input and n_edge)
+          early = self.use_bperm and (p.is_input or age > 0) and not (
+              p.is_input and self.n_edge)
           (_early if early else _pre).append(line)
           shifted[key] = tmp
         return shifted[key]
 
       body: List[str] = []
-      dst_slot = slot_of(n, k, 0)
-      if cfg.interleave and not stage.stmt.let:
+      dst_slot = self.slot_of(n, k, 0)
+      if self.cfg.interleave and not stage.stmt.let:
         # all cells of the row tile at once, operation-major
-        cells = [(j, e) for j in rows_of(n) for e in range(V)]
+        cells = [(j, e) for j in self.rows_of(n) for e in range(self.V)]
 
         def mk_load(j, e, _stage=stage):
           def load(ref: ir.Ref) -> str:
@@ -689,8 +721,8 @@ def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
         for (j, e), r in zip(cells, results):
           body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
                       (n.var, dst_slot, j, e, n.ctype, r))
-      for j in ([] if (cfg.interleave and not stage.stmt.let) else rows_of(n)):
-        for e in range(V):
+      for j in ([] if (self.cfg.interleave and not stage.stmt.let) else self.rows_of(n)):
+        for e in range(self.V):
 
           def load(ref: ir.Ref, _e=e, _j=j, _stage=stage) -> str:
             off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
@@ -710,105 +742,108 @@ def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
             body.append('      %s = (%s)(%s);' %
                         (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
       if guard:
-        w('      if (%s) {  // wave-uniform' % guard)
-        L.extend(early)
+        self.w('      if (%s) {  // wave-uniform' % guard)
+        self.L.extend(early)
       elif early:
         # place them in front of the previous stage's block of this tick
-        L[stage_mark:stage_mark] = early
-      stage_mark = len(L)
-      L.extend(pre)
-      L.extend(body)
+        self.L[stage_mark:stage_mark] = early
+      stage_mark = len(self.L)
+      self.L.extend(pre)
+      self.L.extend(body)
       if guard:
-        w('      }')
+        self.w('      }')
         shifted = {}
       if n.to_lds:   # hand the new plane to the next wave of the block
-        w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][lane * '
-          '%d], %s_s%d_r0);' % (n.ctype, V, n.var, 2 * R - 1, V, n.var,
+        self.w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][lane * '
+          '%d], %s_s%d_r0);' % (n.ctype, self.V, n.var, 2 * self.R - 1, self.V, n.var,
                                 dst_slot))
       # 3. store the outputs of the last iteration
       if n.store_slot is not None:
         oname = stage.name
-        if buf:
-          es = esz[oname]
-          w('      {')
-          w('        const int m = t - %d;' % n.delay)
-          w('        const bool m_ok = m >= m_begin && m < m_end;')
-          for j in range(max(n.rmargin[0], rhalo_lo),
-                         rows_in - max(n.rmargin[1], rhalo_hi)):
+        if self.buf:
+          es = self.esz[oname]
+          self.w('      {')
+          self.w('        const int m = t - %d;' % n.delay)
+          self.w('        const bool m_ok = m >= m_begin && m < m_end;')
+          for j in range(max(n.rmargin[0], self.rhalo_lo),
+                         self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
             reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
-            if dim == 3:
-              w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
+            if self.dim == 3:
+              self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
                 '< n1) ? (unsigned)(m - m_begin) * pitch_b%d + (unsigned)(y0 + '
                 '%d) * pitch_yb%d : SODA_OOB_ROW) + sxb%d, %s);' %
-                (n.ctype, V, nt_s, oname, j, es, j, es, es, reg))
+                (n.ctype, self.V, self.nt_s, oname, j, es, j, es, es, reg))
             else:
-              w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? '
+              self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? '
                 '(unsigned)(m - m_begin) * pitch_b%d : SODA_OOB_ROW) + sxb%d, '
-                '%s);' % (n.ctype, V, nt_s, oname, es, es, reg))
-          w('      }')
+                '%s);' % (n.ctype, self.V, self.nt_s, oname, es, es, reg))
+          self.w('      }')
           continue
-        w('      {')
-        w('        const int m = t - %d;' % n.delay)
-        w('        if (store_ok && m >= m_begin && m < m_end) {')
-        for j in range(max(n.rmargin[0], rhalo_lo),
-                       rows_in - max(n.rmargin[1], rhalo_hi)):
+        self.w('      {')
+        self.w('        const int m = t - %d;' % n.delay)
+        self.w('        if (store_ok && m >= m_begin && m < m_end) {')
+        for j in range(max(n.rmargin[0], self.rhalo_lo),
+                       self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
           reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
-          if dim == 3:
-            w('          if (y0 + %d < n1) soda_store_frag<%s, %d, %s>(q_%s + '
+          if self.dim == 3:
+            self.w('          if (y0 + %d < n1) soda_store_frag<%s, %d, %s>(q_%s + '
               '(int64_t)m * pitch + (int64_t)(y0 + %d) * pitch_y, %s);' %
-              (j, n.ctype, V, nt_s, oname, j, reg))
+              (j, n.ctype, self.V, self.nt_s, oname, j, reg))
           else:
-            w('          soda_store_frag<%s, %d, %s>(q_%s + (int64_t)m * pitch, '
-              '%s);' % (n.ctype, V, nt_s, oname, reg))
-        w('        }')
-        w('      }')
-    shift_temps = max(shift_temps, len(shifted))
-    w('    }')
-   w('  }')
-   if W > 1:
-     w('  }')
-  w('}')
+            self.w('          soda_store_frag<%s, %d, %s>(q_%s + (int64_t)m * pitch, '
+              '%s);' % (n.ctype, self.V, self.nt_s, oname, reg))
+        self.w('        }')
+        self.w('      }')
+    self.shift_temps = max(self.shift_temps, len(shifted))
+    self.w('    }')
 
-  if shift_temps > MAX_SHIFT_TEMPS:
-    raise util.SemanticError(
-        'march: %d lane-shifted operands per row step (> %d); the taps reach '
-        'too far along dim 0 for %d cells per lane' %
-        (shift_temps, MAX_SHIFT_TEMPS, V))
-  est_regs += shift_temps
-  if dim == 2:
-    tile = (strip_cells * wx, cfg.chunk_rows * cfg.waves_y)
-  else:
-    tile = (strip_cells, tile_rows, cfg.chunk_rows)
-  lds_pad = 0
-  if cfg.occupancy:
-    blocks_per_cu = max(1, 4 * cfg.occupancy // waves)
-    # smallest allocation of which blocks_per_cu + 1 no longer fit
-    lds_pad = min(65536, (LDS_PER_CU // (blocks_per_cu + 1)) // 1024 * 1024
-                  + 1024)
-  idx = mod.add_kernel(
-      KernelDesc(name, (block, 1, 1), tile, lds_bytes=lds_pad,
-                 note='%s %s' % (kind, cfg.key()),
-                 tune=dict(axis=ax, waves_along=cfg.waves_y if dim == 2 else 1,
-                           waves_per_block=waves, warm=warm,
-                           fixed=cfg.chunk_fixed, occupancy=cfg.occupancy,
-                           pipe=W,
-                           window_extra=(m_hi - m_lo) if buf else None,
-                           max_elem=max(esz.values()))),
-      '\n'.join(L) + '\n')
-  table = st.symbol_table
-  bytes_in = sum(table[i].size_in_bytes for i in st.input_names)
-  bytes_out = sum(table[o].size_in_bytes for o in st.output_names)
-  redundancy = (64.0 / strip_lanes) * (
-      (cfg.chunk_rows + warm) / float(cfg.chunk_rows)) * (
-          rows_in / float(tile_rows))
-  p = PassDesc(
-      T, [idx], kind,
-      dict(bytes_per_cell_min=bytes_in + bytes_out,
-           read_redundancy=redundancy, strip_cells=strip_cells, warm_rows=warm,
-           unroll=U, edge=edge, rows_in=rows_in, tile_rows=tile_rows,
-           est_window_regs=est_regs))
-  mod.passes.append(p)
-  return p
+  def _finish(self) -> PassDesc:
+    if self.shift_temps > MAX_SHIFT_TEMPS:
+      raise util.SemanticError(
+          'march: %d lane-shifted operands per row step (> %d); the taps reach '
+          'too far along dim 0 for %d cells per lane' %
+          (self.shift_temps, MAX_SHIFT_TEMPS, self.V))
+    self.est_regs += self.shift_temps
+    if self.dim == 2:
+      tile = (self.strip_cells * self.wx, self.cfg.chunk_rows * self.cfg.waves_y)
+    else:
+      tile = (self.strip_cells, self.tile_rows, self.cfg.chunk_rows)
+    lds_pad = 0
+    if self.cfg.occupancy:
+      blocks_per_cu = max(1, 4 * self.cfg.occupancy // self.waves)
+      # smallest allocation of which blocks_per_cu + 1 no longer fit
+      lds_pad = min(65536, (LDS_PER_CU // (blocks_per_cu + 1)) // 1024 * 1024
+                    + 1024)
+    idx = self.mod.add_kernel(
+        KernelDesc(self.name, (self.block, 1, 1), tile, lds_bytes=lds_pad,
+                   note='%s %s' % (self.kind, self.cfg.key()),
+                   tune=dict(axis=self.ax, waves_along=self.cfg.waves_y if self.dim == 2 else 1,
+                             waves_per_block=self.waves, warm=self.warm,
+                             fixed=self.cfg.chunk_fixed, occupancy=self.cfg.occupancy,
+                             pipe=self.W,
+                             window_extra=(self.m_hi - self.m_lo) if self.buf else None,
+                             max_elem=max(self.esz.values()))),
+        '\n'.join(self.L) + '\n')
+    table = self.st.symbol_table
+    bytes_in = sum(table[i].size_in_bytes for i in self.st.input_names)
+    bytes_out = sum(table[o].size_in_bytes for o in self.st.output_names)
+    redundancy = (64.0 / self.strip_lanes) * (
+        (self.cfg.chunk_rows + self.warm) / float(self.cfg.chunk_rows)) * (
+            self.rows_in / float(self.tile_rows))
+    p = PassDesc(
+        self.T, [idx], self.kind,
+        dict(bytes_per_cell_min=bytes_in + bytes_out,
+             read_redundancy=redundancy, strip_cells=self.strip_cells, warm_rows=self.warm,
+             unroll=self.U, edge=self.edge, rows_in=self.rows_in, tile_rows=self.tile_rows,
+             est_window_regs=self.est_regs))
+    self.mod.passes.append(p)
+    return p
+
+
+def add_march_pass(mod: Module, cfg: MarchConfig) -> PassDesc:
+  """Adds one marching kernel (and its pass) for `cfg.fused_iters` iterations;
+  raises SemanticError if the program or the shape does not fit."""
+  return _MarchKernel(mod, cfg).emit()
 
 
 add_march2d_pass = add_march_pass
