@@ -632,170 +632,177 @@ class _MarchKernel:
           (n.ctype, self.V, n.var, self.slot_of(n, k, 0), n.mirror_of.var, self.R, 2 * self.R - 1,
            self.V))
     # 2. compute every tensor's new plane
-    shifted: Dict[Tuple[str, int, int, int, int], str] = {}
-    stage_mark = len(self.L)
+    self._shifted: Dict[Tuple[str, int, int, int, int], str] = {}
+    self._stage_mark = len(self.L)
     for n in self.nodes:
-      if n.stage is None or n.owner != wv:
-        continue
-      stage = n.stage
-      pre: List[str] = []
-      guard = None
-      if self.cfg.warm_guards and self.back_lo[id(n)] is not None:
-        first = self.back_lo[id(n)] + n.delay   # tick offset from m_begin
-        if first > self.m_lo:                   # the loop starts at m_begin + m_lo
-          guard = 't >= m_begin + (%d)' % first
-          shifted = {}                     # temporaries live inside the guard
-
-      early: List[str] = []
-
-      def operand(pname: str, off: Tuple[int, ...], j: int, e: int, _n=n,
-                  _k=k, _pre=pre, _early=early) -> str:
-        p = _n.parents[pname]
-        age = _n.delay - off[self.ax] - p.fill_delay
-        slot = self.slot_of(p, _k, age)
-        row = j + (off[1] if self.dim == 3 else 0)
-        if row < p.rmargin[0] or row >= self.rows_in - p.rmargin[1]:
-          raise util.InternalError('march: row %d of %s is not held' %
-                                   (row, p.var))
-        reg = '%s_s%d_r%d' % (p.var, slot, row)
-        c = e + off[0]
-        lane_off, sub = c // self.V, c % self.V
-        src = '%s[%d]' % (reg, sub)
-        if lane_off == 0:
-          return src
-        if self.cfg.lane_shift == 'none':
-          return src       # TIMING EXPERIMENTS ONLY: wrong results
-        key = (p.var, slot, row, sub, lane_off)
-        if key not in shifted:
-          tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',
-                                    abs(lane_off))
-          if p.is_input and self.n_edge:
-            if abs(lane_off) != 1:
-              raise util.InternalError('march: edge loads reach one lane')
-            # cell index relative to the strip end, served by the edge lane
-            ei = (-c - 1) if lane_off < 0 else (c - self.V)
-            old = '%s_e[%d]' % (reg, ei) if 0 <= ei < self.n_edge else '(%s)0' % p.ctype
-            expr = ('soda_lane_dn_or(%s, %s)' if lane_off < 0 else
-                    'soda_lane_up_or(%s, %s)') % (src, old)
-          elif self.use_bperm:
-            expr = src
-            for _ in range(abs(lane_off)):
-              expr = 'soda_lane_from(%s, %s)' % (
-                  'lane_dn_addr' if lane_off < 0 else 'lane_up_addr', expr)
-          else:
-            expr = src
-            for _ in range(abs(lane_off)):
-              expr = ('soda_lane_dn(%s)' if lane_off < 0 else
-                      'soda_lane_up(%s)') % expr
-          line = '      const %s %s = %s;' % (p.ctype, tmp, expr)
-          # a shift of a row produced in an EARLIER tick can be issued ahead
-          # of the previous stage's arithmetic (latency hidden behind it)
-          early = self.use_bperm and (p.is_input or age > 0) and not (
-              p.is_input and self.n_edge)
-          (_early if early else _pre).append(line)
-          shifted[key] = tmp
-        return shifted[key]
-
-      body: List[str] = []
-      dst_slot = self.slot_of(n, k, 0)
-      if self.cfg.interleave and not stage.stmt.let:
-        # all cells of the row tile at once, operation-major
-        cells = [(j, e) for j in self.rows_of(n) for e in range(self.V)]
-
-        def mk_load(j, e, _stage=stage):
-          def load(ref: ir.Ref) -> str:
-            off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
-            return operand(ref.name, off, j, e)
-          return load
-
-        counter = [0]
-
-        def fresh(_n=n, _k=k) -> str:
-          counter[0] += 1
-          return 'v_%s_k%d_%d' % (_n.var, _k, counter[0])
-
-        stmts, results = ir.c_statements(stage.stmt.expr,
-                                         [mk_load(j, e) for j, e in cells],
-                                         fresh)
-        body.extend('      ' + x for x in stmts)
-        for (j, e), r in zip(cells, results):
-          body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
-                      (n.var, dst_slot, j, e, n.ctype, r))
-      for j in ([] if (self.cfg.interleave and not stage.stmt.let) else self.rows_of(n)):
-        for e in range(self.V):
-
-          def load(ref: ir.Ref, _e=e, _j=j, _stage=stage) -> str:
-            off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
-            return operand(ref.name, off, _j, _e)
-
-          dst = '%s_s%d_r%d[%d]' % (n.var, dst_slot, j, e)
-          if stage.stmt.let:
-            body.append('      {')
-            for let in stage.stmt.let:
-              body.append('        const %s %s = %s;' %
-                          (let.haoda_type.c_type, let.name,
-                           ir.c_expr(let.expr, load)))
-            body.append('        %s = (%s)(%s);' %
-                        (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
-            body.append('      }')
-          else:
-            body.append('      %s = (%s)(%s);' %
-                        (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
-      if guard:
-        self.w('      if (%s) {  // wave-uniform' % guard)
-        self.L.extend(early)
-      elif early:
-        # place them in front of the previous stage's block of this tick
-        self.L[stage_mark:stage_mark] = early
-      stage_mark = len(self.L)
-      self.L.extend(pre)
-      self.L.extend(body)
-      if guard:
-        self.w('      }')
-        shifted = {}
-      if n.to_lds:   # hand the new plane to the next wave of the block
-        self.w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][lane * '
-          '%d], %s_s%d_r0);' % (n.ctype, self.V, n.var, 2 * self.R - 1, self.V, n.var,
-                                dst_slot))
-      # 3. store the outputs of the last iteration
-      if n.store_slot is not None:
-        oname = stage.name
-        if self.buf:
-          es = self.esz[oname]
-          self.w('      {')
-          self.w('        const int m = t - %d;' % n.delay)
-          self.w('        const bool m_ok = m >= m_begin && m < m_end;')
-          for j in range(max(n.rmargin[0], self.rhalo_lo),
-                         self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
-            reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
-            if self.dim == 3:
-              self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
-                '< n1) ? (unsigned)(m - m_begin) * pitch_b%d + (unsigned)(y0 + '
-                '%d) * pitch_yb%d : SODA_OOB_ROW) + sxb%d, %s);' %
-                (n.ctype, self.V, self.nt_s, oname, j, es, j, es, es, reg))
-            else:
-              self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? '
-                '(unsigned)(m - m_begin) * pitch_b%d : SODA_OOB_ROW) + sxb%d, '
-                '%s);' % (n.ctype, self.V, self.nt_s, oname, es, es, reg))
-          self.w('      }')
-          continue
-        self.w('      {')
-        self.w('        const int m = t - %d;' % n.delay)
-        self.w('        if (store_ok && m >= m_begin && m < m_end) {')
-        for j in range(max(n.rmargin[0], self.rhalo_lo),
-                       self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
-          reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
-          if self.dim == 3:
-            self.w('          if (y0 + %d < n1) soda_store_frag<%s, %d, %s>(q_%s + '
-              '(int64_t)m * pitch + (int64_t)(y0 + %d) * pitch_y, %s);' %
-              (j, n.ctype, self.V, self.nt_s, oname, j, reg))
-          else:
-            self.w('          soda_store_frag<%s, %d, %s>(q_%s + (int64_t)m * pitch, '
-              '%s);' % (n.ctype, self.V, self.nt_s, oname, reg))
-        self.w('        }')
-        self.w('      }')
-    self.shift_temps = max(self.shift_temps, len(shifted))
+      if n.stage is not None and n.owner == wv:
+        self._emit_stage(n, k)
+    self.shift_temps = max(self.shift_temps, len(self._shifted))
     self.w('    }')
+
+  def _emit_stage(self, n: _Node, k: int) -> None:
+    """One tensor's new plane at tick phase k: lane-shifted operands first
+    (shared by the stages of a tick), then one statement per cell."""
+    stage = n.stage
+    pre: List[str] = []
+    guard = None
+    if self.cfg.warm_guards and self.back_lo[id(n)] is not None:
+      first = self.back_lo[id(n)] + n.delay   # tick offset from m_begin
+      if first > self.m_lo:                   # the loop starts at m_begin + m_lo
+        guard = 't >= m_begin + (%d)' % first
+        self._shifted = {}                     # temporaries live inside the guard
+
+    early: List[str] = []
+
+    def operand(pname: str, off: Tuple[int, ...], j: int, e: int, _n=n,
+                _k=k, _pre=pre, _early=early) -> str:
+      p = _n.parents[pname]
+      age = _n.delay - off[self.ax] - p.fill_delay
+      slot = self.slot_of(p, _k, age)
+      row = j + (off[1] if self.dim == 3 else 0)
+      if row < p.rmargin[0] or row >= self.rows_in - p.rmargin[1]:
+        raise util.InternalError('march: row %d of %s is not held' %
+                                 (row, p.var))
+      reg = '%s_s%d_r%d' % (p.var, slot, row)
+      c = e + off[0]
+      lane_off, sub = c // self.V, c % self.V
+      src = '%s[%d]' % (reg, sub)
+      if lane_off == 0:
+        return src
+      if self.cfg.lane_shift == 'none':
+        return src       # TIMING EXPERIMENTS ONLY: wrong results
+      key = (p.var, slot, row, sub, lane_off)
+      if key not in self._shifted:
+        tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',
+                                  abs(lane_off))
+        if p.is_input and self.n_edge:
+          if abs(lane_off) != 1:
+            raise util.InternalError('march: edge loads reach one lane')
+          # cell index relative to the strip end, served by the edge lane
+          ei = (-c - 1) if lane_off < 0 else (c - self.V)
+          old = '%s_e[%d]' % (reg, ei) if 0 <= ei < self.n_edge else '(%s)0' % p.ctype
+          expr = ('soda_lane_dn_or(%s, %s)' if lane_off < 0 else
+                  'soda_lane_up_or(%s, %s)') % (src, old)
+        elif self.use_bperm:
+          expr = src
+          for _ in range(abs(lane_off)):
+            expr = 'soda_lane_from(%s, %s)' % (
+                'lane_dn_addr' if lane_off < 0 else 'lane_up_addr', expr)
+        else:
+          expr = src
+          for _ in range(abs(lane_off)):
+            expr = ('soda_lane_dn(%s)' if lane_off < 0 else
+                    'soda_lane_up(%s)') % expr
+        line = '      const %s %s = %s;' % (p.ctype, tmp, expr)
+        # a shift of a row produced in an EARLIER tick can be issued ahead
+        # of the previous stage's arithmetic (latency hidden behind it)
+        early = self.use_bperm and (p.is_input or age > 0) and not (
+            p.is_input and self.n_edge)
+        (_early if early else _pre).append(line)
+        self._shifted[key] = tmp
+      return self._shifted[key]
+
+    body: List[str] = []
+    dst_slot = self.slot_of(n, k, 0)
+    if self.cfg.interleave and not stage.stmt.let:
+      # all cells of the row tile at once, operation-major
+      cells = [(j, e) for j in self.rows_of(n) for e in range(self.V)]
+
+      def mk_load(j, e, _stage=stage):
+        def load(ref: ir.Ref) -> str:
+          off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
+          return operand(ref.name, off, j, e)
+        return load
+
+      counter = [0]
+
+      def fresh(_n=n, _k=k) -> str:
+        counter[0] += 1
+        return 'v_%s_k%d_%d' % (_n.var, _k, counter[0])
+
+      stmts, results = ir.c_statements(stage.stmt.expr,
+                                       [mk_load(j, e) for j, e in cells],
+                                       fresh)
+      body.extend('      ' + x for x in stmts)
+      for (j, e), r in zip(cells, results):
+        body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
+                    (n.var, dst_slot, j, e, n.ctype, r))
+    for j in ([] if (self.cfg.interleave and not stage.stmt.let) else self.rows_of(n)):
+      for e in range(self.V):
+
+        def load(ref: ir.Ref, _e=e, _j=j, _stage=stage) -> str:
+          off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
+          return operand(ref.name, off, _j, _e)
+
+        dst = '%s_s%d_r%d[%d]' % (n.var, dst_slot, j, e)
+        if stage.stmt.let:
+          body.append('      {')
+          for let in stage.stmt.let:
+            body.append('        const %s %s = %s;' %
+                        (let.haoda_type.c_type, let.name,
+                         ir.c_expr(let.expr, load)))
+          body.append('        %s = (%s)(%s);' %
+                      (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
+          body.append('      }')
+        else:
+          body.append('      %s = (%s)(%s);' %
+                      (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
+    if guard:
+      self.w('      if (%s) {  // wave-uniform' % guard)
+      self.L.extend(early)
+    elif early:
+      # place them in front of the previous stage's block of this tick
+      self.L[self._stage_mark:self._stage_mark] = early
+    self._stage_mark = len(self.L)
+    self.L.extend(pre)
+    self.L.extend(body)
+    if guard:
+      self.w('      }')
+      self._shifted = {}
+    if n.to_lds:   # hand the new plane to the next wave of the block
+      self.w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][lane * '
+        '%d], %s_s%d_r0);' % (n.ctype, self.V, n.var, 2 * self.R - 1, self.V, n.var,
+                              dst_slot))
+    if n.store_slot is not None:
+      self._emit_store(n, stage.name, dst_slot)
+
+  def _emit_store(self, n: _Node, oname: str, dst_slot: int) -> None:
+    """Stores the new plane of a last-iteration output (rows and lanes that
+    are not this wave's to write are dropped by the addressing)."""
+    if self.buf:
+      es = self.esz[oname]
+      self.w('      {')
+      self.w('        const int m = t - %d;' % n.delay)
+      self.w('        const bool m_ok = m >= m_begin && m < m_end;')
+      for j in range(max(n.rmargin[0], self.rhalo_lo),
+                     self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
+        reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
+        if self.dim == 3:
+          self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
+            '< n1) ? (unsigned)(m - m_begin) * pitch_b%d + (unsigned)(y0 + '
+            '%d) * pitch_yb%d : SODA_OOB_ROW) + sxb%d, %s);' %
+            (n.ctype, self.V, self.nt_s, oname, j, es, j, es, es, reg))
+        else:
+          self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? '
+            '(unsigned)(m - m_begin) * pitch_b%d : SODA_OOB_ROW) + sxb%d, '
+            '%s);' % (n.ctype, self.V, self.nt_s, oname, es, es, reg))
+      self.w('      }')
+      return
+    self.w('      {')
+    self.w('        const int m = t - %d;' % n.delay)
+    self.w('        if (store_ok && m >= m_begin && m < m_end) {')
+    for j in range(max(n.rmargin[0], self.rhalo_lo),
+                   self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
+      reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
+      if self.dim == 3:
+        self.w('          if (y0 + %d < n1) soda_store_frag<%s, %d, %s>(q_%s + '
+          '(int64_t)m * pitch + (int64_t)(y0 + %d) * pitch_y, %s);' %
+          (j, n.ctype, self.V, self.nt_s, oname, j, reg))
+      else:
+        self.w('          soda_store_frag<%s, %d, %s>(q_%s + (int64_t)m * pitch, '
+          '%s);' % (n.ctype, self.V, self.nt_s, oname, reg))
+    self.w('        }')
+    self.w('      }')
 
   def _finish(self) -> PassDesc:
     if self.shift_temps > MAX_SHIFT_TEMPS:
