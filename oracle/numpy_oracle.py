@@ -288,16 +288,21 @@ def run(stencil: core.Stencil, inputs: Dict[str, np.ndarray],
       raise util.InputError('input %s must be %s' % (name, t.np_name))
     cur[name] = arr
 
+  preserve = stencil.preserve_border
+  stencil.check_preserve()
   in_boxes = None
   result = {}
   for it in range(iterate):
-    boxes = stencil.iteration_boxes(in_boxes)
+    # border: preserve -- every iteration starts from fully defined inputs
+    boxes = stencil.iteration_boxes(None if preserve else in_boxes)
     tensors = dict(cur)
     for stage in stencil.ordered_stages:
       wlo, whi = boxes[stage.name]
       lo = tuple(max(0, -l) for l in wlo)
       hi = tuple(n - max(0, h) for n, h in zip(extent, whi))
       out = np.zeros(first.shape, dtype=np.dtype(stage.haoda_type.np_name))
+      if preserve and stage.is_output:
+        out[...] = cur[stencil.preserved_from(stage.name)]
       if all(h > l for l, h in zip(lo, hi)):
         st = stage.st_idx
 

@@ -13,6 +13,30 @@ from soda_amd.codegen.hip.module import (KernelDesc, Module, PassDesc, _COORDS)
 DIRECT_BLOCK = 256
 
 
+def _interior(st: core.Stencil, stage: core.Stage):
+  """(lo, hi, keep): cells at least `lo[d]` from the low and `hi[d]` from the
+  high end of every dimension are computed; the others get 0 -- or, for an
+  output under `border: preserve`, the value of input `keep` (core.py
+  check_preserve), in which case the margins are those of the window ONE
+  iteration spans back to the program inputs, not just this stage's taps."""
+  dim = st.dim
+  lo = [0] * dim
+  hi = [0] * dim
+  for parent in stage.taps:
+    tlo, thi = stage.tap_bounds(parent)
+    for d in range(dim):
+      lo[d] = max(lo[d], -tlo[d])
+      hi[d] = max(hi[d], thi[d])
+  keep = None
+  if st.preserve_border and stage.is_output:
+    keep = st.preserved_from(stage.name)
+    wlo, whi = st.interior_bounds(stage.name)
+    for d in range(dim):
+      lo[d] = max(lo[d], -wlo[d])
+      hi[d] = max(hi[d], whi[d])
+  return lo, hi, keep
+
+
 def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
                         vec: int) -> Tuple[List[str], Tuple[int, ...]]:
   """`direct` with `vec` cells per thread: every row of a parent the stage taps
@@ -26,13 +50,9 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
   dim = st.dim
   table = st.symbol_table
   parents = list(stage.taps)
-  lo = [0] * dim
-  hi = [0] * dim
-  for parent in parents:
-    tlo, thi = stage.tap_bounds(parent)
-    for d in range(dim):
-      lo[d] = max(lo[d], -tlo[d])
-      hi[d] = max(hi[d], thi[d])
+  lo, hi, keep = _interior(st, stage)
+  if keep is not None and keep not in parents:
+    parents.append(keep)
   ct = stage.haoda_type.c_type
   V = vec
   L = [
@@ -65,7 +85,11 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
     if hi[d]:
       outer.append('%s < a.extent[%d] - %d' % (_COORDS[d], d, hi[d]))
   L.append('  %s soda_r[%d];' % (ct, V))
-  L.append('  soda_zero_frag<%s, %d>(soda_r);' % (ct, V))
+  if keep is None:
+    L.append('  soda_zero_frag<%s, %d>(soda_r);' % (ct, V))
+  else:    # border: preserve -- cells that are not computed keep the input
+    L.append('  soda_load_frag<%s, %d, false>(soda_r, in_%s + soda_o);' %
+             (ct, V, keep))
   L.append('  const bool soda_rows_ok = %s;' %
            (' && '.join(outer) if outer else 'true'))
   L.append('  if (soda_rows_ok && %s >= %d && %s + %d < a.extent[0] - %d) {' %
@@ -95,10 +119,10 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
           if off[d]:
             terms.append('(%d) * a.stride[%d]' % (off[d], d))
         body.append('%s %s[%d];' % (pt, var, n))
-        body.append('{ const %s* __restrict__ p = in_%s + (%s);' %
+        body.append('{ const %s* __restrict__ soda_p = in_%s + (%s);' %
                     (pt, ref.name, ' + '.join(terms)))
         body.append('  _Pragma("unroll") for (int i = 0; i < %d; ++i) '
-                    '%s[i] = p[i]; }' % (n, var))
+                    '%s[i] = soda_p[i]; }' % (n, var))
         rows[key] = (var, mn)
       var, mn = rows[key]
       return '%s[%d]' % (var, off[0] - mn + e)
@@ -153,13 +177,9 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
                      note='direct rows V%d' % vec), '\n'.join(lines) + '\n'))
       continue
     parents = list(stage.taps)
-    lo = [0] * dim
-    hi = [0] * dim
-    for parent in parents:
-      tlo, thi = stage.tap_bounds(parent)
-      for d in range(dim):
-        lo[d] = max(lo[d], -tlo[d])
-        hi[d] = max(hi[d], thi[d])
+    lo, hi, keep = _interior(st, stage)
+    if keep is not None and keep not in parents:
+      parents.append(keep)
     lines = [
         '// stage `%s`: %s' % (stage.name,
                                ' '.join(str(stage.stmt).split())),
@@ -190,7 +210,10 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
         conds.append('%s >= %d' % (_COORDS[d], lo[d]))
       if hi[d]:
         conds.append('%s < a.extent[%d] - %d' % (_COORDS[d], d, hi[d]))
-    lines.append('  %s soda_r = (%s)0;' % (ct, ct))
+    if keep is None:
+      lines.append('  %s soda_r = (%s)0;' % (ct, ct))
+    else:   # border: preserve -- cells that are not computed keep the input
+      lines.append('  %s soda_r = in_%s[soda_o];' % (ct, keep))
     lines.append('  if (%s) {' % (' && '.join(conds) if conds else 'true'))
 
     def load(ref: ir.Ref, _stage=stage) -> str:

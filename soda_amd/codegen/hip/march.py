@@ -7,6 +7,7 @@ from soda_amd import core, ir, util
 from soda_amd.codegen.hip.module import KernelDesc, Module, PassDesc
 
 MAX_UNROLL = 24        # tallest register window (planes) a marching wave holds
+MAX_FUSE_PRESERVE = 8      # deepest temporal blocking under `border: preserve`
 MAX_FUSE_3D = 2            # deepest temporal blocking of the 3-D kernels
 MAX_SHIFT_TEMPS = 64       # lane-shifted operand copies per row step
 REG_BUDGET = 160           # estimated VGPRs (windows + shifted copies) a shape may need
@@ -36,6 +37,23 @@ class _Node:
     self.owner = 0
     self.mirror_of: Optional['_Node'] = None
     self.to_lds = False         # some wave mirrors this tensor
+    # border: preserve -- DSL name of the input whose value this output keeps
+    # on cells one iteration cannot compute (it is then also a parent, tapped
+    # at offset 0)
+    self.keep: Optional[str] = None
+
+  def tap_bounds(self, pname: str):
+    """Bounds of the taps on parent `pname`, the offset-0 tap of a preserved
+    border included."""
+    dim = len(self.stage.st_idx)
+    if pname in self.stage.taps:
+      lo, hi = self.stage.tap_bounds(pname)
+    else:
+      lo, hi = (0,) * dim, (0,) * dim
+    if pname == self.keep:
+      lo = tuple(min(0, v) for v in lo)
+      hi = tuple(max(0, v) for v in hi)
+    return lo, hi
 
   @property
   def is_input(self) -> bool:
@@ -196,6 +214,9 @@ def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
       n.owner = owner
       for parent in stage.taps:
         n.parents[parent] = env[parent]
+      if st.preserve_border and stage.is_output:
+        n.keep = st.preserved_from(stage.name)
+        n.parents.setdefault(n.keep, env[n.keep])
       env[stage.name] = n
       nodes.append(n)
     last_outputs = {o: env[o] for o in st.output_names}
@@ -217,7 +238,7 @@ def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
     margin = [0, 0]
     rmargin = [0, 0]
     for pname, p in n.parents.items():
-      tlo, thi = n.stage.tap_bounds(pname)
+      tlo, thi = n.tap_bounds(pname)
       d = p.delay + thi[ax]
       delay = d if delay is None else max(delay, d)
       margin[0] = max(margin[0], p.margin[0] + max(0, -tlo[0]))
@@ -234,7 +255,7 @@ def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
     if n.stage is None:
       continue
     for pname, p in n.parents.items():
-      tlo, _ = n.stage.tap_bounds(pname)
+      tlo, _ = n.tap_bounds(pname)
       p.window = max(p.window, n.delay - tlo[ax] - p.fill_delay + 1)
   return nodes, inputs, last_outputs
 
@@ -353,7 +374,7 @@ class _MarchKernel:
       if n.stage is None or self.back_lo[id(n)] is None:
         continue
       for pname, pnode in n.parents.items():
-        tlo, _ = n.stage.tap_bounds(pname)
+        tlo, _ = n.tap_bounds(pname)
         cand = self.back_lo[id(n)] + tlo[self.ax]
         if self.back_lo[id(pnode)] is None or cand < self.back_lo[id(pnode)]:
           self.back_lo[id(pnode)] = cand
@@ -520,6 +541,14 @@ class _MarchKernel:
           self.w('  const int64_t eoff%d = edge_ok%d ? (int64_t)(ex%d - x0c) : 0;' %
             (i, i, i))
 
+    if self.st.preserve_border:
+      # border: preserve -- which of a lane's cells lie outside the columns one
+      # iteration can compute (the same for every fused iteration)
+      for o in self.st.output_names:
+        wlo, whi = self.st.interior_bounds(o)
+        for e in range(self.V):
+          self.w('  const bool keepx_%s_%d = !(x0 + %d >= %d && x0 + %d < n0 - %d);'
+                 % (o, e, e, max(0, -wlo[0]), e, max(0, whi[0])))
     self.use_bperm = self.cfg.lane_shift == 'bperm'
     if self.use_bperm:
       self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
@@ -753,6 +782,28 @@ class _MarchKernel:
     elif early:
       # place them in front of the previous stage's block of this tick
       self.L[self._stage_mark:self._stage_mark] = early
+    if n.keep is not None:
+      # border: preserve -- cells one iteration cannot compute keep the value
+      # of the input this output replaces (same cell, previous iteration)
+      wlo, whi = self.st.interior_bounds(stage.name)
+      zero = (0,) * self.dim
+      body.append('      {')
+      body.append('        const int mk = t - %d;' % n.delay)
+      body.append('        const bool keep_m = !(mk >= %d && mk < nm - %d);' %
+                  (max(0, -wlo[self.ax]), max(0, whi[self.ax])))
+      for j in self.rows_of(n):
+        keep_row = 'keep_m'
+        if self.dim == 3:
+          body.append('        const bool keep_r%d = keep_m || !(y0 + %d >= %d '
+                      '&& y0 + %d < n1 - %d);' %
+                      (j, j, max(0, -wlo[1]), j, max(0, whi[1])))
+          keep_row = 'keep_r%d' % j
+        for e in range(self.V):
+          dst = '%s_s%d_r%d[%d]' % (n.var, dst_slot, j, e)
+          body.append('        %s = (%s || keepx_%s_%d) ? %s : %s;' %
+                      (dst, keep_row, stage.name, e,
+                       operand(n.keep, zero, j, e), dst))
+      body.append('      }')
     self._stage_mark = len(self.L)
     self.L.extend(pre)
     self.L.extend(body)

@@ -292,7 +292,47 @@ class Stencil:
     first output) is defined after `iterate` iterations on a grid of `extent`
     (loop bounds of reference frt/host.py:570-577)."""
     name = name or self.output_names[0]
+    if self.preserve_border:
+      # outputs are defined everywhere (their border cells carry the input
+      # they replace); locals only where one iteration can compute them
+      if name in self.output_names:
+        return (0,) * self.dim, tuple(extent)
+      return self.interior_box(extent, name)
     lo, hi = self.window_bounds(iterate)[name]
+    return (tuple(max(0, -l) for l in lo),
+            tuple(n - max(0, h) for n, h in zip(extent, hi)))
+
+  # -- border: preserve -----------------------------------------------------
+  # The reference parses and stores `border: preserve` (grammar.py:32,
+  # core.py:56-57) but no live code path implements it.  Here it means: in
+  # every iteration, an output cell outside the box ONE iteration can compute
+  # takes the value of the input that output replaces (outputs pair with
+  # inputs by position, as `iterate` pairs them), so boundary values persist
+  # and the defined region does not shrink with the iteration count.
+  def check_preserve(self) -> None:
+    """Raises unless `border: preserve` is well defined for this program."""
+    if not self.preserve_border:
+      return
+    if (len(self.input_stmts) != len(self.output_stmts) or
+        self.input_types != self.output_types):
+      raise util.SemanticError(
+          'border: preserve copies every output\'s border from the input it '
+          'replaces: it needs as many outputs as inputs, of the same types '
+          '(inputs %s, outputs %s)' % (util.lst2str(self.input_types),
+                                      util.lst2str(self.output_types)))
+
+  def preserved_from(self, output: str) -> str:
+    """The input whose values `output` keeps on its border."""
+    return self.input_names[self.output_names.index(output)]
+
+  def interior_bounds(self, name: str) -> Box:
+    """Window of `name` over ONE iteration, relative to that iteration's
+    inputs (what decides where a cell can be computed under preserve)."""
+    return self.iteration_boxes()[name]
+
+  def interior_box(self, extent: Sequence[int], name: str
+                   ) -> Tuple[Tuple[int, ...], Tuple[int, ...]]:
+    lo, hi = self.interior_bounds(name)
     return (tuple(max(0, -l) for l in lo),
             tuple(n - max(0, h) for n, h in zip(extent, hi)))
 

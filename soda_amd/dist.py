@@ -35,6 +35,10 @@ class Slab:
       raise util.InputError('bad rank %d of %d' % (rank, world))
     if exchange_every < 1:
       raise util.InputError('exchange_every must be >= 1')
+    if stencil.preserve_border and world > 1:
+      raise util.SemanticError(
+          'border: preserve is not supported across slabs yet (the kernels '
+          'take the grid edge for the border)')
     self.stencil = stencil
     self.extent = tuple(extent)
     self.world = world

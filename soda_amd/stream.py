@@ -150,6 +150,10 @@ class StreamProgram:
     allows it, False = always the linear form."""
     if stencil.param_stmts:
       raise util.SemanticError('stream mode does not support param tensors')
+    if stencil.preserve_border:
+      raise util.SemanticError(
+          'stream mode does not support border: preserve (tile edges are not '
+          'grid borders)')
     self.stencil = stencil
     self.device = device
     self.flat = linearize(stencil)

@@ -69,3 +69,47 @@ def test_gpu_matches_oracle(built, seed):
       assert np.array_equal(g, w, equal_nan=True), (
           'seed %d, %s (%s), output %s: %d cells differ\n%s' %
           (seed, strategy, kinds, o, int((g != w).sum()), text))
+
+
+def _build_preserve(seed):
+  """The same random program with `border: preserve` (iterable programs only:
+  every output needs the input it replaces)."""
+  text, dim, iterate = fuzz.program(seed)
+  try:
+    stencil = core.from_text(text, border='preserve')
+    stencil.check_preserve()
+  except util.SodaError:
+    pytest.skip('not a program border: preserve applies to')
+  return text, stencil, fuzz.extent_for(seed, dim)
+
+
+@pytest.mark.parametrize('seed', CPU_SEEDS)
+def test_oracles_agree_with_preserved_border(seed):
+  from oracle import c_oracle, numpy_oracle
+  text, stencil, extent = _build_preserve(seed)
+  ins = fuzz.inputs_for(stencil, extent, seed)
+  a = numpy_oracle.run(stencil, ins)
+  b = c_oracle.COracle(stencil, openmp=False).run(ins)
+  for o in stencil.output_names:
+    assert np.array_equal(a[o], b[o], equal_nan=True), text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', GPU_SEEDS)
+def test_gpu_matches_oracle_with_preserved_border(built, seed):
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  text, stencil, extent = _build_preserve(seed)
+  ins = fuzz.inputs_for(stencil, extent, seed)
+  want = c_oracle.COracle(stencil, openmp=False).run(ins)
+  for strategy in ('auto', 'direct'):
+    with runtime.Program(stencil, lower.LowerOptions(strategy=strategy,
+                                                     fuse=(2,)),
+                         extent=extent) as prog:
+      got = prog.run(ins)
+      kinds = sorted({p.kind for p in prog.module.passes})
+    for o in stencil.output_names:     # the WHOLE grid is defined
+      assert np.array_equal(got[o], want[o], equal_nan=True), (
+          'seed %d, %s (%s), output %s: %d cells differ\n%s' %
+          (seed, strategy, kinds, o, int((got[o] != want[o]).sum()), text))

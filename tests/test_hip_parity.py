@@ -467,3 +467,27 @@ def test_stage_pipelined_blocks(built, name, iterate, fuse, pipe, extent):
   mod = lower.lower(stencil, lower.LowerOptions(fuse=(fuse,), pipe=pipe, vec=4))
   assert any('_pipe%d' % pipe in k.name for k in mod.kernels)
   _check(stencil, extent, opts, oracle='c')
+
+
+@pytest.mark.parametrize('name,iterate,opts,extent', [
+    ('jacobi2d.soda', 1, dict(), (520, 61)),
+    ('jacobi2d.soda', 9, dict(fuse=(4,)), (520, 61)),          # 4 + 4 + 1
+    ('jacobi2d.soda', 12, dict(fuse=(12,)), (1000, 130)),
+    ('jacobi2d.soda', 8, dict(fuse=(8,), pipe=4), (776, 90)),
+    ('jacobi2d.soda', 5, dict(strategy='direct'), (260, 33)),
+    ('seidel2d.soda', 6, dict(fuse=(3,)), (300, 77)),
+    ('blur.soda', 3, dict(fuse=(3,)), (640, 50)),              # box through a local
+    ('blur.soda', 2, dict(strategy='direct'), (640, 50)),
+    ('coupled2d.soda', 4, dict(fuse=(2,)), (300, 90)),         # two paired tensors
+    ('heat3d.soda', 5, dict(fuse=(2,)), (300, 24, 40)),
+    ('jacobi3d.soda', 3, dict(strategy='direct'), (64, 20, 18)),
+])
+def test_border_preserve(built, name, iterate, opts, extent):
+  """`border: preserve` (defined by this build, core.Stencil.check_preserve):
+  the whole grid is defined after any number of iterations and equals the
+  oracle bit for bit, border cells included."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate, border='preserve')
+  assert stencil.valid_box(extent) == ((0,) * stencil.dim, tuple(extent))
+  _check(stencil, extent, lower.LowerOptions(**opts), oracle='c')

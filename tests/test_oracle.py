@@ -219,3 +219,64 @@ def test_compare_rule():
   b = a.copy()
   b[3, 3] += 1
   assert numpy_oracle.compare(b, a, (0, 0), (4, 4)) == 1
+
+
+# -- border: preserve (this build's definition; the reference only parses it) --
+@pytest.mark.parametrize('name,iterate,extent', [
+    ('jacobi2d.soda', 3, (37, 21)),
+    ('blur.soda', 2, (40, 17)),            # two stages: box through the local
+    ('heat3d.soda', 2, (12, 11, 9)),
+    ('seidel2d.soda', 4, (33, 20)),
+])
+def test_preserve_border_oracles_agree(name, iterate, extent):
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path(name), iterate=iterate, border='preserve')
+  rng = np.random.default_rng(3)
+  ins = {n: (rng.random(tuple(extent[::-1])).astype(t.np_name) if t.is_float
+             else rng.integers(0, 1000, tuple(extent[::-1])).astype(t.np_name))
+         for n, t in zip(st.input_names, st.input_types)}
+  a = numpy_oracle.run(st, ins)
+  b = c_oracle.COracle(st, openmp=False).run(ins)
+  plain = core.from_file(soda_path(name), iterate=1)
+  one = numpy_oracle.run(core.from_file(soda_path(name), iterate=1,
+                                        border='preserve'), ins)
+  ref1 = numpy_oracle.run(plain, ins)
+  for o, i in zip(st.output_names, st.input_names):
+    assert np.array_equal(a[o].view(np.uint8), b[o].view(np.uint8))
+    assert st.valid_box(extent, o) == ((0,) * st.dim, tuple(extent))
+    # one iteration: the plain result inside its box, the input outside
+    lo, hi = plain.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(one[o][idx], ref1[o][idx])
+    mask = np.ones(one[o].shape, bool)
+    mask[idx] = False
+    assert np.array_equal(one[o][mask], ins[i][mask])
+    # any number of iterations: the outermost layer is the input's
+    rim = np.ones(a[o].shape, bool)
+    rim[tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))] = False
+    assert np.array_equal(a[o][rim], ins[i][rim])
+
+
+def test_preserve_border_heat3d_ramp_is_a_fixed_point_everywhere():
+  """heat3d's weights are powers of two summing to 1: a linear ramp is exactly
+  reproduced inside, and preserved on the border -> output == input on the
+  WHOLE grid for any iteration count."""
+  from oracle import numpy_oracle
+  st = core.from_file(soda_path('heat3d.soda'), iterate=5, border='preserve')
+  r, q, p = np.meshgrid(np.arange(10), np.arange(13), np.arange(16),
+                        indexing='ij')
+  a = (p + q + r).astype(np.float32)
+  out = numpy_oracle.run(st, {st.input_names[0]: a})
+  assert np.array_equal(out[st.output_names[0]], a)
+
+
+def test_preserve_border_needs_paired_tensors():
+  from oracle import numpy_oracle
+  from soda_amd import util
+  st = core.from_text(
+      'kernel: k\nburst width: 64\nunroll factor: 2\niterate: 1\n'
+      'border: preserve\ninput float: a(32, *)\ninput float: b\n'
+      'output float: c(0, 0) = a(0, 1) + b(0, -1)\n')
+  with pytest.raises(util.SemanticError, match='border: preserve'):
+    numpy_oracle.run(st, {'a': np.zeros((4, 4), np.float32),
+                          'b': np.zeros((4, 4), np.float32)})

@@ -15,13 +15,14 @@ ap.add_argument('--iterate', type=int, default=None)
 ap.add_argument('--fuse', type=int, nargs='*', default=[])
 ap.add_argument('--strategy', default='auto')
 ap.add_argument('--reps', type=int, default=3)
-ap.add_argument('--pipe', type=int, default=1)
+ap.add_argument('--pipe', type=int, default=None)
+ap.add_argument('--border', default=None)
 ap.add_argument('--pipe-rows', type=int, default=2)
 ap.add_argument('--shift', default='dpp')
 ap.add_argument('--chunk', type=int, default=0)
 args = ap.parse_args()
 path = args.soda if os.path.exists(args.soda) else os.path.join(ROOT, 'tests/golden/soda', args.soda)
-st = core.from_file(path, iterate=args.iterate)
+st = core.from_file(path, iterate=args.iterate, border=args.border)
 T = {'float32': torch.float32, 'float64': torch.float64, 'uint16': torch.int16, 'int16': torch.int16, 'int32': torch.int32, 'uint8': torch.uint8}
 shape = tuple(args.extent[::-1])
 dev = torch.device('cuda', 0)
