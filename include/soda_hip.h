@@ -49,12 +49,13 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 2
+#define SODA_HIP_ABI_VERSION 3
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
 #define SODA_HIP_MAX_KERNELS 32
 #define SODA_HIP_MAX_PASSES 8
 #define SODA_HIP_MAX_PASS_KERNELS 16
+#define SODA_HIP_MAX_PARAMS 8
 #define SODA_HIP_NAME_LEN 64
 
 enum soda_hip_status {
@@ -103,7 +104,13 @@ typedef struct soda_hip_plan {
   int32_t num_inputs;
   int32_t num_outputs;
   int32_t num_locals;                  /* scratch tensors the library owns */
-  int32_t elem_size[SODA_HIP_MAX_TENSORS];  /* bytes per element, by slot */
+  int32_t num_params;                  /* `param` arrays (ref grammar.py:41-45,
+                                          frt/host.py:72-78): small read-only
+                                          arrays, C order, the same for every
+                                          iteration */
+  int32_t param_elems[SODA_HIP_MAX_PARAMS];  /* elements per param array */
+  /* slots: inputs, outputs, locals, params -- bytes per element of each */
+  int32_t elem_size[SODA_HIP_MAX_TENSORS];
   int32_t num_kernels;
   soda_hip_kernel_desc_t kernels[SODA_HIP_MAX_KERNELS];
   int32_t num_passes;                  /* sorted by fused_iters, largest first;
@@ -143,7 +150,10 @@ int soda_hip_program_destroy(soda_hip_program_t* program);
  * dense (dim-0-fastest) arrays of `extent`.  outputs first, then inputs, as in
  * the reference ABI.  Inputs are never written.  Asynchronous on `stream`
  * (a hipStream_t, or NULL for the default stream); scratch buffers are owned
- * by the program and reused across calls. */
+ * by the program and reused across calls.  `inputs` holds the num_inputs
+ * tensors followed by the num_params param arrays (device pointers to
+ * param_elems[k] elements each), the order of the reference's operator
+ * signature (frt/host.py:72-78: inputs, outputs, then params). */
 int soda_hip_run_device(soda_hip_program_t* program, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,
                         int32_t iterate, void* stream);
@@ -158,6 +168,8 @@ typedef struct soda_hip_host_tensor {
   const int32_t* stride;
   const int32_t* min;      /* accepted, unused (as in the reference) */
 } soda_hip_host_tensor_t;
+/* `inputs`: the num_inputs tensors, then one entry per param array of which
+ * only `ptr` is read (param_elems[k] contiguous elements). */
 int soda_hip_run_host(soda_hip_program_t* program,
                       const soda_hip_host_tensor_t* inputs,
                       const soda_hip_host_tensor_t* outputs, int32_t iterate);

@@ -272,8 +272,16 @@ def run(stencil: core.Stencil, inputs: Dict[str, np.ndarray],
   iterate = stencil.iterate if iterate is None else iterate
   if iterate > 1 and len(stencil.input_names) != len(stencil.output_names):
     raise util.SemanticError('iterate > 1 needs as many outputs as inputs')
-  if stencil.param_stmts:
-    raise util.SemanticError('oracle: param tensors are not supported')
+  # `param` arrays ride in `inputs` under their names, C order (element
+  # name(i, j) = array[i][j]); a scalar param is a 0-d or 1-element array
+  params = {}
+  for p in stencil.param_stmts:
+    arr = np.ascontiguousarray(inputs[p.name]).reshape(-1)
+    if arr.dtype != np.dtype(p.haoda_type.np_name) or \
+        arr.size != stencil.param_elems(p):
+      raise util.InputError('param %s must be %d x %s' % (
+          p.name, stencil.param_elems(p), p.haoda_type.np_name))
+    params[p.name] = (arr, p)
   first = inputs[stencil.input_names[0]]
   extent = first.shape[::-1]
   dim = stencil.dim
@@ -307,12 +315,17 @@ def run(stencil: core.Stencil, inputs: Dict[str, np.ndarray],
         st = stage.st_idx
 
         def load(ref, _lo=lo, _hi=hi, _st=st):
+          if ref.name in params:
+            arr, pstmt = params[ref.name]
+            return (arr[stencil.param_index(pstmt, ref.idx)],
+                    ctype_of(pstmt.haoda_type))
           off = tuple(a - b for a, b in zip(ref.idx, _st))
           parent = tensors[ref.name]
           return (parent[_box_slices(_lo, _hi, off)],
                   ctype_of(stencil.symbol_table[ref.name]))
 
-        lets = {}
+        lets = {name: (arr[0], ctype_of(pstmt.haoda_type))
+                for name, (arr, pstmt) in params.items() if not pstmt.size}
         ev = _Eval(load, lets)
         for let in stage.stmt.let:
           v, t = ev(let.expr)

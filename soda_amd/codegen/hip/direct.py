@@ -75,6 +75,7 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
     pt = table[parent].c_type
     L.append('  const %s* __restrict__ in_%s = (const %s*)a.buf[%d];' %
              (pt, parent, pt, mod.slot[parent]))
+  L.extend(mod.param_decls(stage))
   L.append('  const int64_t soda_o = %s;' % ' + '.join(
       ['(int64_t)%s' % _COORDS[0]] +
       ['(int64_t)%s * a.stride[%d]' % (_COORDS[d], d) for d in range(1, dim)]))
@@ -99,6 +100,8 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
   rows: Dict[Tuple[str, Tuple[int, ...]], Tuple[str, int]] = {}
   spans: Dict[Tuple[str, Tuple[int, ...]], List[int]] = {}
   for ref in ir.get_loads(stage.stmt.expr):
+    if ref.name in st.param_names:
+      continue
     off = tuple(a - b for a, b in zip(ref.idx, stage.st_idx))
     key = (ref.name, off[1:])
     sp = spans.setdefault(key, [off[0], off[0]])
@@ -107,6 +110,9 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
 
   def mk_load(e: int):
     def load(ref: ir.Ref) -> str:
+      prm = mod.param_load(ref)
+      if prm is not None:
+        return prm
       off = tuple(a - b for a, b in zip(ref.idx, stage.st_idx))
       key = (ref.name, off[1:])
       if key not in rows:
@@ -135,7 +141,7 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
     return 'v%d' % counter[0]
 
   _, results = ir.c_statements(stage.stmt.expr, [mk_load(e) for e in range(V)],
-                               fresh, stmts=body)
+                               fresh, var=mod.param_var, stmts=body)
   L.extend('    ' + x for x in body)
   for e, r in enumerate(results):
     L.append('    soda_r[%d] = (%s)(%s);' % (e, ct, r))
@@ -143,6 +149,9 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
 
   # ---- strip ends: one cell at a time, as the scalar kernel ------------------
   def scalar_load(ref: ir.Ref) -> str:
+    prm = mod.param_load(ref)
+    if prm is not None:
+      return prm
     terms = ['soda_o', 'e']
     for d in range(dim):
       off = ref.idx[d] - stage.st_idx[d]
@@ -155,7 +164,7 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
   L.append('      if (%s + e >= %d && %s + e < a.extent[0] - %d)' %
            (_COORDS[0], lo[0], _COORDS[0], hi[0]))
   L.append('        soda_r[e] = (%s)(%s);' %
-           (ct, ir.c_expr(stage.stmt.expr, scalar_load)))
+           (ct, ir.c_expr(stage.stmt.expr, scalar_load, mod.param_var)))
   L.append('    }')
   L.append('  }')
   L.append('  soda_store_frag<%s, %d, false>(out + soda_o, soda_r);' % (ct, V))
@@ -201,6 +210,7 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
       pt = table[parent].c_type
       lines.append('  const %s* __restrict__ in_%s = (const %s*)a.buf[%d];' %
                    (pt, parent, pt, mod.slot[parent]))
+    lines.extend(mod.param_decls(stage))
     lines.append('  const int64_t soda_o = %s;' % ' + '.join(
         ['(int64_t)%s' % _COORDS[0]] +
         ['(int64_t)%s * a.stride[%d]' % (_COORDS[d], d) for d in range(1, dim)]))
@@ -217,6 +227,9 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
     lines.append('  if (%s) {' % (' && '.join(conds) if conds else 'true'))
 
     def load(ref: ir.Ref, _stage=stage) -> str:
+      prm = mod.param_load(ref)
+      if prm is not None:
+        return prm
       terms = ['soda_o']
       for d in range(dim):
         off = ref.idx[d] - _stage.st_idx[d]
@@ -227,8 +240,10 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
 
     for let in stage.stmt.let:
       lines.append('    const %s %s = %s;' %
-                   (let.haoda_type.c_type, let.name, ir.c_expr(let.expr, load)))
-    lines.append('    soda_r = (%s)(%s);' % (ct, ir.c_expr(stage.stmt.expr, load)))
+                   (let.haoda_type.c_type, let.name,
+                    ir.c_expr(let.expr, load, mod.param_var)))
+    lines.append('    soda_r = (%s)(%s);' %
+                 (ct, ir.c_expr(stage.stmt.expr, load, mod.param_var)))
     lines.append('  }')
     lines.append('  out[soda_o] = soda_r;')
     lines.append('}')

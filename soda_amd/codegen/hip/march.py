@@ -169,8 +169,6 @@ def march_supported(stencil: core.Stencil) -> Optional[str]:
   """None if the marching kernels can run the program, else why not."""
   if stencil.dim not in (2, 3):
     return 'the marching kernels need a 2- or 3-dimensional program'
-  if stencil.param_stmts:
-    return 'param tensors'
   return None
 
 
@@ -553,6 +551,12 @@ class _MarchKernel:
     if self.use_bperm:
       self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
       self.w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
+    declared = set()
+    for stage in self.st.ordered_stages:      # `param` arrays: plain pointers
+      for line in self.mod.param_decls(stage):
+        if line not in declared:
+          declared.add(line)
+          self.w(line)
     for n in self.nodes:
       if n.to_lds:     # written at tick t, read by the next wave at tick t + R
         self.w('  __shared__ %s soda_ring_%s[%d][%d];' % (n.ctype, n.var, 2 * self.R,
@@ -739,6 +743,9 @@ class _MarchKernel:
 
       def mk_load(j, e, _stage=stage):
         def load(ref: ir.Ref) -> str:
+          prm = self.mod.param_load(ref)
+          if prm is not None:
+            return prm
           off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
           return operand(ref.name, off, j, e)
         return load
@@ -751,7 +758,7 @@ class _MarchKernel:
 
       stmts, results = ir.c_statements(stage.stmt.expr,
                                        [mk_load(j, e) for j, e in cells],
-                                       fresh)
+                                       fresh, var=self.mod.param_var)
       body.extend('      ' + x for x in stmts)
       for (j, e), r in zip(cells, results):
         body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
@@ -760,6 +767,9 @@ class _MarchKernel:
       for e in range(self.V):
 
         def load(ref: ir.Ref, _e=e, _j=j, _stage=stage) -> str:
+          prm = self.mod.param_load(ref)
+          if prm is not None:
+            return prm
           off = tuple(a - b for a, b in zip(ref.idx, _stage.st_idx))
           return operand(ref.name, off, _j, _e)
 
@@ -769,13 +779,15 @@ class _MarchKernel:
           for let in stage.stmt.let:
             body.append('        const %s %s = %s;' %
                         (let.haoda_type.c_type, let.name,
-                         ir.c_expr(let.expr, load)))
+                         ir.c_expr(let.expr, load, self.mod.param_var)))
           body.append('        %s = (%s)(%s);' %
-                      (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
+                      (dst, n.ctype, ir.c_expr(stage.stmt.expr, load,
+                                               self.mod.param_var)))
           body.append('      }')
         else:
           body.append('      %s = (%s)(%s);' %
-                      (dst, n.ctype, ir.c_expr(stage.stmt.expr, load)))
+                      (dst, n.ctype, ir.c_expr(stage.stmt.expr, load,
+                                               self.mod.param_var)))
     if guard:
       self.w('      if (%s) {  // wave-uniform' % guard)
       self.L.extend(early)

@@ -33,7 +33,7 @@ class Stage:
   Offsets are relative to the produced cell (load idx - store idx), which is
   how the reference's loop nest addresses parents (frt/host.py:587-594)."""
 
-  def __init__(self, stmt, is_output: bool):
+  def __init__(self, stmt, is_output: bool, param_names: Sequence[str] = ()):
     self.stmt = stmt
     self.name = stmt.name
     self.haoda_type = stmt.haoda_type
@@ -41,8 +41,17 @@ class Stage:
     self.st_idx = stmt.ref.idx
     nodes = [l.expr for l in stmt.let] + [stmt.expr]
     self.loads = ir.get_load_dict(nodes)
+    # `param` arrays are not tensors of the grid: their elements are addressed
+    # absolutely, they take no part in windows, boxes or the stage DAG
+    self.params = [p for p in self.loads if p in param_names]
+    for node in nodes:
+      for v in ir.get_vars(node):
+        if v.name in param_names and v.name not in self.params:
+          self.params.append(v.name)
     self.taps: Dict[str, List[Tuple[int, ...]]] = collections.OrderedDict()
     for parent, refs in self.loads.items():
+      if parent in param_names:
+        continue
       seen = []
       for r in refs:
         off = tuple(a - b for a, b in zip(r.idx, self.st_idx))
@@ -121,18 +130,33 @@ class Stencil:
             raise util.SemanticError(
                 '`%s` is loaded with %d indices in a %d-dimensional program' %
                 (ref.name, len(ref.idx), self.dim))
+          if ref.name in self.param_names:
+            size = self.param_table[ref.name].size
+            if len(ref.idx) != len(size) or not all(
+                0 <= i < n for i, n in zip(ref.idx, size)):
+              raise util.SemanticError(
+                  '`%s` reads element (%s) of param `%s%s`' %
+                  (stmt.name, ', '.join(map(str, ref.idx)), ref.name,
+                   ''.join('[%d]' % n for n in size)))
         for var in ir.get_vars(expr):
           if var.name not in lets and var.name not in self.param_names:
             raise util.SemanticError('`%s` uses unknown variable `%s`' %
                                      (stmt.name, var.name))
+          if var.name in self.param_names and var.name not in lets and \
+              self.param_table[var.name].size:
+            raise util.SemanticError(
+                '`%s` uses param array `%s` without an index' %
+                (stmt.name, var.name))
         if isinstance(node, ir.Let):
           lets.add(node.name)
+    typed = dict(table)
+    typed.update((p.name, p.haoda_type) for p in self.param_stmts)
     for stmt in self.local_stmts + self.output_stmts:
-      stmt.propagate_type(table)
+      stmt.propagate_type(typed)
 
     self.stages: List[Stage] = (
-        [Stage(s, False) for s in self.local_stmts] +
-        [Stage(s, True) for s in self.output_stmts])
+        [Stage(s, False, self.param_names) for s in self.local_stmts] +
+        [Stage(s, True, self.param_names) for s in self.output_stmts])
     self._check_dag()
 
   # -- names and types -----------------------------------------------------
@@ -147,6 +171,27 @@ class Stencil:
   @property
   def param_names(self):
     return tuple(s.name for s in self.param_stmts)
+
+  @property
+  def param_table(self):
+    return {s.name: s for s in self.param_stmts}
+
+  @staticmethod
+  def param_index(stmt, idx: Sequence[int]) -> int:
+    """Element `name(i, j, ...)` of `param T: name[s0][s1]...` is the C array
+    element name[i][j]... (row-major: the reference host declares and fills
+    it that way, frt/host.py:497-541); a scalar param has the single index 0."""
+    lin = 0
+    for i, n in zip(idx, stmt.size):
+      lin = lin * n + i
+    return lin
+
+  @staticmethod
+  def param_elems(stmt) -> int:
+    n = 1
+    for v in stmt.size:
+      n *= v
+    return n
 
   @property
   def local_names(self):

@@ -74,6 +74,7 @@ struct soda_hip_program {
   std::vector<DeviceBuffer> locals;   // one per local tensor
   std::vector<DeviceBuffer> temps;    // one per output: iteration ping-pong
   std::vector<DeviceBuffer> host_in;  // run_host staging on the device
+  std::vector<DeviceBuffer> host_prm; // ... of the param arrays
   std::vector<DeviceBuffer> host_out;
   int32_t last_launches = 0;
   int32_t last_fused = 0;
@@ -187,13 +188,18 @@ static int check_plan(const soda_hip_plan_t* p) {
   if (p->dim < 1 || p->dim > SODA_HIP_MAX_DIM)
     return fail(SODA_HIP_ERR_INVALID, "plan: bad dim");
   if (p->num_inputs < 1 || p->num_outputs < 1 || p->num_locals < 0 ||
-      p->num_inputs + p->num_outputs + p->num_locals > SODA_HIP_MAX_TENSORS)
+      p->num_params < 0 || p->num_params > SODA_HIP_MAX_PARAMS ||
+      p->num_inputs + p->num_outputs + p->num_locals + p->num_params >
+          SODA_HIP_MAX_TENSORS)
     return fail(SODA_HIP_ERR_INVALID, "plan: bad tensor counts");
+  for (int k = 0; k < p->num_params; ++k)
+    if (p->param_elems[k] < 1)
+      return fail(SODA_HIP_ERR_INVALID, "plan: bad param size");
   if (p->num_kernels < 1 || p->num_kernels > SODA_HIP_MAX_KERNELS)
     return fail(SODA_HIP_ERR_INVALID, "plan: bad kernel count");
   if (p->num_passes < 1 || p->num_passes > SODA_HIP_MAX_PASSES)
     return fail(SODA_HIP_ERR_INVALID, "plan: bad pass count");
-  int slots = p->num_inputs + p->num_outputs + p->num_locals;
+  int slots = p->num_inputs + p->num_outputs + p->num_locals + p->num_params;
   for (int s = 0; s < slots; ++s)
     if (p->elem_size[s] < 1 || p->elem_size[s] > 16)
       return fail(SODA_HIP_ERR_INVALID, "plan: bad element size");
@@ -268,6 +274,7 @@ int soda_hip_program_create(const void* code, size_t code_size,
   p->locals.resize(plan->num_locals);
   p->temps.resize(plan->num_outputs);
   p->host_in.resize(plan->num_inputs);
+  p->host_prm.resize(plan->num_params);
   p->host_out.resize(plan->num_outputs);
   *program = p;
   return SODA_HIP_OK;
@@ -276,7 +283,8 @@ int soda_hip_program_create(const void* code, size_t code_size,
 int soda_hip_program_destroy(soda_hip_program_t* p) {
   if (!p) return SODA_HIP_OK;
   (void)hipSetDevice(p->device);
-  for (auto* v : {&p->locals, &p->temps, &p->host_in, &p->host_out})
+  for (auto* v : {&p->locals, &p->temps, &p->host_in, &p->host_out,
+                  &p->host_prm})
     for (auto& b : *v)
       if (b.ptr) (void)hipFree(b.ptr);
   if (p->module) (void)hipModuleUnload(p->module);
@@ -330,7 +338,7 @@ int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
     base.stride[d] = cells;
     cells *= e;
   }
-  for (int i = 0; i < plan.num_inputs; ++i)
+  for (int i = 0; i < plan.num_inputs + plan.num_params; ++i)
     if (!inputs[i]) return fail(SODA_HIP_ERR_INVALID, "run_device: NULL input");
   for (int i = 0; i < plan.num_outputs; ++i)
     if (!outputs[i]) return fail(SODA_HIP_ERR_INVALID, "run_device: NULL output");
@@ -352,6 +360,9 @@ int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
   if (remaining) return fail(SODA_HIP_ERR_INVALID, "iterate not schedulable");
 
   const int in0 = 0, out0 = plan.num_inputs, loc0 = out0 + plan.num_outputs;
+  const int prm0 = loc0 + plan.num_locals;
+  for (int k = 0; k < plan.num_params; ++k)   // the same in every iteration
+    base.buf[prm0 + k] = const_cast<void*>(inputs[plan.num_inputs + k]);
   for (int l = 0; l < plan.num_locals; ++l) {
     int rc = ensure(p->locals[l], (size_t)cells * plan.elem_size[loc0 + l]);
     if (rc) return rc;
@@ -500,6 +511,16 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
     int rc = ensure(p->host_out[o], bytes);
     if (rc) return rc;
     out_ptrs[o] = p->host_out[o].ptr;
+  }
+  const int prm0 = plan.num_inputs + plan.num_outputs + plan.num_locals;
+  for (int k = 0; k < plan.num_params; ++k) {
+    const soda_hip_host_tensor_t& t = inputs[plan.num_inputs + k];
+    if (!t.ptr) return fail(SODA_HIP_ERR_INVALID, "run_host: NULL param");
+    size_t bytes = (size_t)plan.param_elems[k] * plan.elem_size[prm0 + k];
+    int rc = ensure(p->host_prm[k], bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p->host_prm[k].ptr, t.ptr, bytes, hipMemcpyHostToDevice));
+    in_ptrs.push_back(p->host_prm[k].ptr);
   }
   int rc = soda_hip_run_device(p, out_ptrs.data(), in_ptrs.data(), extent,
                                iterate, nullptr);

@@ -37,8 +37,9 @@ MAX_TENSORS = 16
 MAX_KERNELS = 32
 MAX_PASSES = 8
 MAX_PASS_KERNELS = 16
+MAX_PARAMS = 8
 NAME_LEN = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KernelDesc(ctypes.Structure):
@@ -59,6 +60,8 @@ class Plan(ctypes.Structure):
   _fields_ = [('abi_version', ctypes.c_int32), ('dim', ctypes.c_int32),
               ('num_inputs', ctypes.c_int32), ('num_outputs', ctypes.c_int32),
               ('num_locals', ctypes.c_int32),
+              ('num_params', ctypes.c_int32),
+              ('param_elems', ctypes.c_int32 * MAX_PARAMS),
               ('elem_size', ctypes.c_int32 * MAX_TENSORS),
               ('num_kernels', ctypes.c_int32),
               ('kernels', KernelDesc * MAX_KERNELS),
@@ -223,6 +226,11 @@ def make_plan(mod: lower.Module) -> Plan:
   plan.num_inputs = len(st.input_names)
   plan.num_outputs = len(st.output_names)
   plan.num_locals = len(st.local_names)
+  if len(st.param_stmts) > MAX_PARAMS:
+    raise util.SemanticError('more than %d param arrays' % MAX_PARAMS)
+  plan.num_params = len(st.param_stmts)
+  for i, pstmt in enumerate(st.param_stmts):
+    plan.param_elems[i] = st.param_elems(pstmt)
   if len(mod.elem_size) > MAX_TENSORS:
     raise util.SemanticError('more than %d tensors' % MAX_TENSORS)
   for i, s in enumerate(mod.elem_size):
@@ -486,12 +494,13 @@ class Program:
                  extent: Sequence[int], iterate: Optional[int] = None,
                  stream: int = 0) -> None:
     """`outputs` / `inputs` are device addresses (e.g. tensor.data_ptr()) of
-    dense dim-0-fastest arrays; asynchronous on `stream`."""
+    dense dim-0-fastest arrays; asynchronous on `stream`.  `inputs` holds the
+    input tensors followed by the program's `param` arrays (C order)."""
     st = self.stencil
     iterate = st.iterate if iterate is None else iterate
     self._check_extent(extent)
     if len(outputs) != len(st.output_names) or len(inputs) != len(
-        st.input_names):
+        st.input_names) + len(st.param_stmts):
       raise util.InputError('wrong number of tensors')
     outs = (ctypes.c_void_p * len(outputs))(*outputs)
     ins = (ctypes.c_void_p * len(inputs))(*inputs)
@@ -539,10 +548,17 @@ class Program:
       keep.extend((ext, strd, mn, arr))
       return HostTensor(arr.ctypes.data, ext, strd, mn)
 
-    ins = (HostTensor * len(st.input_names))(*[
-        describe(np.asarray(inputs[n]), t.np_name)
-        for n, t in zip(st.input_names, st.input_types)
-    ])
+    in_list = [describe(np.asarray(inputs[n]), t.np_name)
+               for n, t in zip(st.input_names, st.input_types)]
+    for pstmt in st.param_stmts:        # param arrays follow, C order
+      arr = np.ascontiguousarray(inputs[pstmt.name]).reshape(-1)
+      if arr.dtype != np.dtype(pstmt.haoda_type.np_name) or \
+          arr.size != st.param_elems(pstmt):
+        raise util.InputError('param %s must be %d x %s' % (
+            pstmt.name, st.param_elems(pstmt), pstmt.haoda_type.np_name))
+      keep.append(arr)
+      in_list.append(HostTensor(arr.ctypes.data, None, None, None))
+    ins = (HostTensor * len(in_list))(*in_list)
     result = {}
     for n, t in zip(st.output_names, st.output_types):
       if outputs is not None and n in outputs:

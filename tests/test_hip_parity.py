@@ -30,6 +30,11 @@ def _inputs(stencil, extent, seed=0, kind='random'):
       info = np.iinfo(dt)
       out[name] = rng.integers(info.min, int(info.max) + 1, size=shape,
                                dtype=np.int64).astype(dt)
+  for p in stencil.param_stmts:       # param arrays: C order, small values
+    dt = np.dtype(p.haoda_type.np_name)
+    size = p.size or (1,)
+    out[p.name] = (rng.random(size).astype(dt) if p.haoda_type.is_float else
+                   rng.integers(-9, 10, size=size).astype(dt))
   return out
 
 
@@ -491,3 +496,50 @@ def test_border_preserve(built, name, iterate, opts, extent):
   stencil = core.from_file(soda_path(name), iterate=iterate, border='preserve')
   assert stencil.valid_box(extent) == ((0,) * stencil.dim, tuple(extent))
   _check(stencil, extent, lower.LowerOptions(**opts), oracle='c')
+
+
+PARAM3D = """kernel: wsum3d
+burst width: 64
+unroll factor: 2
+iterate: 3
+input float: a(32, 32, *)
+param float: c[2][3]
+param int32: shift
+output float: b(0, 0, 0) = a(0, 0, -1) * c(0, 0) + a(0, -1, 0) * c(0, 1) + a(-1, 0, 0) * c(0, 2) + a(1, 0, 0) * c(1, 0) + a(0, 1, 0) * c(1, 1) + a(0, 0, 1) * c(1, 2) + shift
+"""
+
+PARAM_INT = """kernel: lut2d
+burst width: 64
+unroll factor: 2
+iterate: 1
+input int16: x(32, *)
+param int16: k[4]
+local int32: t(0, 0) = x(0, 0) * k(0) + x(1, 0) * k(1)
+output int16: y(0, 0) = int16((t(0, 0) + t(0, 1) * k(2)) / 4) + k(3)
+"""
+
+
+@pytest.mark.parametrize('text,extent,opts', [
+    (None, (520, 61), dict()),                       # conv2d.soda, iterate 2
+    (None, (520, 61), dict(fuse=(2,))),
+    (None, (260, 33), dict(strategy='direct')),
+    (None, (259, 33), dict(strategy='direct')),      # one cell per thread
+    (PARAM3D, (64, 20, 18), dict()),
+    (PARAM3D, (64, 20, 18), dict(fuse=(2,))),
+    (PARAM3D, (40, 12, 10), dict(strategy='direct')),
+    (PARAM_INT, (512, 40), dict()),
+    (PARAM_INT, (512, 40), dict(strategy='direct')),
+])
+def test_param_arrays(built, text, extent, opts):
+  """`param` arrays (reference grammar.py:41-45; its kernel emitter never
+  delivered them): small read-only arrays addressed absolutely, C order,
+  passed after the inputs."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = (core.from_text(text) if text else
+             core.from_file(soda_path('conv2d.soda')))
+  assert stencil.param_names
+  _check(stencil, extent, lower.LowerOptions(**opts), oracle='c')
+  bordered = (core.from_text(text, border='preserve') if text else
+              core.from_file(soda_path('conv2d.soda'), border='preserve'))
+  _check(bordered, extent, lower.LowerOptions(**opts))

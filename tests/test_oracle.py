@@ -280,3 +280,41 @@ def test_preserve_border_needs_paired_tensors():
   with pytest.raises(util.SemanticError, match='border: preserve'):
     numpy_oracle.run(st, {'a': np.zeros((4, 4), np.float32),
                           'b': np.zeros((4, 4), np.float32)})
+
+
+# -- param arrays ---------------------------------------------------------------
+def test_param_arrays_closed_form_and_oracles_agree():
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path('conv2d.soda'), iterate=1)
+  assert st.param_names == ('w', 'bias')
+  assert [dict(s.taps).keys() for s in st.stages][0] == {'img': 0}.keys()
+  rng = np.random.default_rng(0)
+  ins = {'img': rng.random((20, 30), dtype=np.float32),
+         'w': rng.random((3, 3), dtype=np.float32),
+         'bias': np.array([0.5], np.float32)}
+  a = numpy_oracle.run(st, ins)['out']
+  b = c_oracle.COracle(st, openmp=False).run(ins)['out']
+  assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+  # w(i, j) is the C array element w[i][j]; the sum associates left to right
+  y, x = 7, 9
+  acc = None
+  for dy in (-1, 0, 1):
+    for dx in (-1, 0, 1):
+      term = np.float32(ins['img'][y + dy, x + dx] * ins['w'][dy + 1, dx + 1])
+      acc = term if acc is None else np.float32(acc + term)
+  assert a[y, x] == np.float32(acc + np.float32(0.5))
+  assert st.valid_box((30, 20)) == ((1, 1), (29, 19))
+
+
+@pytest.mark.parametrize('bad,why', [
+    ('w(3, 0)', 'reads element'),          # out of range
+    ('w(0)', 'reads element'),             # wrong arity
+    ('w', 'without an index'),             # array used as a scalar
+])
+def test_param_reference_errors(bad, why):
+  from soda_amd import util
+  text = ('kernel: k\nburst width: 64\nunroll factor: 2\niterate: 1\n'
+          'input float: a(32, *)\nparam float: w[3][3]\n'
+          'output float: b(0, 0) = a(0, 0) * %s\n' % bad)
+  with pytest.raises(util.SemanticError, match=why):
+    core.from_text(text)
