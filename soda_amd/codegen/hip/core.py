@@ -121,6 +121,12 @@ def run(stencil: core.Stencil, args: argparse.Namespace) -> None:
     else:  # p + q (+ r): the reference harness's integer init
       grids = np.indices(shape).sum(axis=0)
       inputs[name] = grids.astype(t.np_name)
+  for pstmt in stencil.param_stmts:
+    # the reference harness's param init: the sum of the indices
+    # (frt/host.py:530-541)
+    size = pstmt.size or (1,)
+    inputs[pstmt.name] = np.indices(size).sum(axis=0).astype(
+        pstmt.haoda_type.np_name)
   prog = runtime.Program(stencil, options_from_args(args),
                          device=args.hip_device, extent=extent)
   t0 = time.time()
