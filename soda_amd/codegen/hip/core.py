@@ -31,7 +31,7 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-strategy', type=str, dest='hip_strategy',
                       choices=('auto', 'direct', 'march', 'lds'), default='auto',
                       help='kernel family: register-marching wavefront strips '
-                      '(2-D programs) or one cell per thread')
+                      '(2-D / 3-D programs) or the direct kernels')
   parser.add_argument('--hip-fuse', type=int, nargs='*', dest='hip_fuse',
                       metavar='T', default=[4],
                       help='temporal blocking: iterations fused per launch')

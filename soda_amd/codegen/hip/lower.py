@@ -5,8 +5,9 @@ src/soda/codegen/xilinx/hls_kernel.py:338-410 `print_code`, :665-886
 `print_module_definition`; src/soda/dataflow.py:336-625) is done here for a
 GPU.  Two families of kernels are generated:
 
-`direct`   one kernel per stage, one cell per thread, parents read straight
-           from global memory (L1/L2 give the reuse).  Handles every program
+`direct`   one kernel per stage, 16 bytes' worth of cells per thread, parents
+           read straight from global memory into per-thread row buffers
+           (L1/L2 give the reuse between threads).  Handles every program
            the front-end accepts (1-4 dimensions, any DAG); locals live in
            HBM scratch.  It is the correctness baseline and the fallback.
 
@@ -212,8 +213,7 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     # read 19 rows) or many live tensors may not fit the register budget at
     # the preferred shape: try shallower prefetch, then fewer cells per lane,
     # and take the first shape whose estimate stays within REG_BUDGET (else
-    # the leanest); only if none exists fall back to one-cell-per-thread
-    # kernels.
+    # the leanest); only if none exists fall back to `direct` kernels.
     pfs = [opts.prefetch] if opts.prefetch else [
         default_prefetch(1) if stencil.dim == 2 else 1, 2, 1]
     pfs = sorted(set(pfs), reverse=True)

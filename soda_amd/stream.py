@@ -140,7 +140,7 @@ class StreamProgram:
   """`<app>_kernel` for one program: banked wire streams in, banked out."""
 
   # narrower tiles leave most of a 64-lane x V-wide marching strip idle and the
-  # one-cell-per-thread linear form wins (heat3d 32x32 tiles: 0.67 vs 1.09 ms)
+  # linear form (`direct` kernels) wins (heat3d 32x32 tiles: 0.50 vs 0.79 ms)
   DENSE_MIN_TILE0 = 256
 
   def __init__(self, stencil: core.Stencil, device: int = 0,
@@ -166,7 +166,7 @@ class StreamProgram:
     #  * as the ORIGINAL n-D program on the stream viewed as a dense array of
     #    extent (tile_size..., rows) -- tiles are whole rows laid end to end --
     #    with the fast marching kernels (built on first use);
-    #  * as the linearised 1-D program (always valid, one cell per thread).
+    #  * as the linearised 1-D program (always valid, `direct` kernels).
     self._linear = {}      # cells per thread -> Program of the 1-D form
     self._linear_program(1)
     self._dense = None

@@ -2,7 +2,7 @@
 
 CPU: the two generic oracle restatements (numpy with explicit C arithmetic,
 generated C compiled by gcc) agree bit for bit.  GPU: every kernel family the
-lowering picks -- and the one-cell-per-thread fallback -- equals the oracle on
+lowering picks -- and the `direct` fallback -- equals the oracle on
 the valid box, bit for bit, for every seed."""
 import numpy as np
 import pytest
