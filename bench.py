@@ -205,7 +205,8 @@ def main():
 
   def step_fn(dst, src, lext, iters):
     prog.run_device([t.data_ptr() for t in dst], [t.data_ptr() for t in src],
-                    lext, iterate=iters, stream=stream)
+                    lext, iterate=iters, stream=stream, origin=slab.origin,
+                    global_extent=slab.extent)
 
   def one_step():
     # a step always starts from the same buffers; ghosts of a_bufs are fresh

@@ -80,6 +80,11 @@ typedef struct soda_hip_kargs {
                                           descriptor's tile: chunk lengths are
                                           run-time values, tuned per GPU/extent
                                           without recompiling) */
+  int32_t origin[SODA_HIP_MAX_DIM];    /* position of the arrays' cell 0 in ... */
+  int32_t gextent[SODA_HIP_MAX_DIM];   /* ... the global grid (a slab of a
+                                          multi-GPU run; = 0 / extent else):
+                                          `border: preserve` is about the
+                                          GLOBAL border */
 } soda_hip_kargs_t;
 
 typedef struct soda_hip_kernel_desc {
@@ -154,6 +159,16 @@ int soda_hip_program_destroy(soda_hip_program_t* program);
  * tensors followed by the num_params param arrays (device pointers to
  * param_elems[k] elements each), the order of the reference's operator
  * signature (frt/host.py:72-78: inputs, outputs, then params). */
+/* Same, for arrays that are a window of a larger grid (one GPU's slab):
+ * `origin` = global position of cell 0 of the arrays, `global_extent` = size
+ * of the whole grid (NULL, NULL = the arrays are the grid).  Only programs
+ * with `border: preserve` look at them. */
+int soda_hip_run_device_window(soda_hip_program_t* program,
+                               void* const* outputs,
+                               const void* const* inputs,
+                               const int32_t* extent, const int32_t* origin,
+                               const int32_t* global_extent, int32_t iterate,
+                               void* stream);
 int soda_hip_run_device(soda_hip_program_t* program, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,
                         int32_t iterate, void* stream);

@@ -265,7 +265,10 @@ def _box_slices(lo: Sequence[int], hi: Sequence[int], off: Sequence[int]):
 
 def run(stencil: core.Stencil, inputs: Dict[str, np.ndarray],
         iterate: Optional[int] = None,
-        keep_locals: bool = False) -> Dict[str, np.ndarray]:
+        keep_locals: bool = False,
+        origin: Optional[Sequence[int]] = None,
+        global_extent: Optional[Sequence[int]] = None
+        ) -> Dict[str, np.ndarray]:
   """Runs `iterate` iterations (default: the program's) and returns the output
   tensors (plus the last iteration's locals if asked), zero outside their
   valid boxes."""
@@ -311,6 +314,20 @@ def run(stencil: core.Stencil, inputs: Dict[str, np.ndarray],
       out = np.zeros(first.shape, dtype=np.dtype(stage.haoda_type.np_name))
       if preserve and stage.is_output:
         out[...] = cur[stencil.preserved_from(stage.name)]
+        if origin is not None:
+          # the arrays are a window (slab) of a larger grid: the border is the
+          # GLOBAL one; cells the window cannot compute keep the input too
+          glo, ghi = stencil.interior_box(global_extent, stage.name)
+          tl = [0] * dim
+          th = [0] * dim
+          for parent in stage.taps:
+            a, b = stage.tap_bounds(parent)
+            for d in range(dim):
+              tl[d] = max(tl[d], -a[d])
+              th[d] = max(th[d], b[d])
+          lo = tuple(max(tl[d], glo[d] - origin[d]) for d in range(dim))
+          hi = tuple(min(extent[d] - th[d], ghi[d] - origin[d])
+                     for d in range(dim))
       if all(h > l for l, h in zip(lo, hi)):
         st = stage.st_idx
 

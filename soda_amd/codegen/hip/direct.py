@@ -15,10 +15,10 @@ DIRECT_BLOCK = 256
 
 def _interior(st: core.Stencil, stage: core.Stage):
   """(lo, hi, keep): cells at least `lo[d]` from the low and `hi[d]` from the
-  high end of every dimension are computed; the others get 0 -- or, for an
-  output under `border: preserve`, the value of input `keep` (core.py
-  check_preserve), in which case the margins are those of the window ONE
-  iteration spans back to the program inputs, not just this stage's taps."""
+  high end of every dimension of the arrays can be computed (their taps lie
+  in the arrays); the others get 0 -- or, for an output under `border:
+  preserve`, the value of input `keep` (core.py check_preserve), as do the
+  cells outside _global_interior()."""
   dim = st.dim
   lo = [0] * dim
   hi = [0] * dim
@@ -30,11 +30,22 @@ def _interior(st: core.Stencil, stage: core.Stage):
   keep = None
   if st.preserve_border and stage.is_output:
     keep = st.preserved_from(stage.name)
-    wlo, whi = st.interior_bounds(stage.name)
-    for d in range(dim):
-      lo[d] = max(lo[d], -wlo[d])
-      hi[d] = max(hi[d], whi[d])
   return lo, hi, keep
+
+
+def _global_interior(st: core.Stencil, stage: core.Stage, coord) -> List[str]:
+  """border: preserve -- C conditions that a cell lies inside the box ONE
+  iteration can compute on the GLOBAL grid (the arrays may be one GPU's slab:
+  kargs origin / gextent).  `coord(d)` spells the local coordinate."""
+  wlo, whi = st.interior_bounds(stage.name)
+  conds = []
+  for d in range(st.dim):
+    if wlo[d] < 0:
+      conds.append('a.origin[%d] + %s >= %d' % (d, coord(d), -wlo[d]))
+    if whi[d] > 0:
+      conds.append('a.origin[%d] + %s < a.gextent[%d] - %d' %
+                   (d, coord(d), d, whi[d]))
+  return conds
 
 
 def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
@@ -91,10 +102,19 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
   else:    # border: preserve -- cells that are not computed keep the input
     L.append('  soda_load_frag<%s, %d, false>(soda_r, in_%s + soda_o);' %
              (ct, V, keep))
+  glob = []      # border: preserve -- the box on the GLOBAL grid
+  if keep is not None:
+    glob = _global_interior(st, stage, lambda d: _COORDS[d])
+    outer += [c for c in glob if 'origin[0]' not in c]
   L.append('  const bool soda_rows_ok = %s;' %
            (' && '.join(outer) if outer else 'true'))
-  L.append('  if (soda_rows_ok && %s >= %d && %s + %d < a.extent[0] - %d) {' %
-           (_COORDS[0], lo[0], _COORDS[0], V - 1, hi[0]))
+  first_ok = ['%s >= %d' % (_COORDS[0], lo[0]),
+              '%s + %d < a.extent[0] - %d' % (_COORDS[0], V - 1, hi[0])]
+  for c in glob:
+    if 'origin[0]' in c:      # all V cells: the first for >=, the last for <
+      first_ok.append(c.replace('+ %s <' % _COORDS[0],
+                                '+ %s + %d <' % (_COORDS[0], V - 1)))
+  L.append('  if (soda_rows_ok && %s) {' % ' && '.join(first_ok))
 
   # ---- all cells interior: shared row buffers --------------------------------
   rows: Dict[Tuple[str, Tuple[int, ...]], Tuple[str, int]] = {}
@@ -161,8 +181,11 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
     return 'in_%s[%s]' % (ref.name, ' + '.join(terms))
 
   L.append('    _Pragma("unroll") for (int e = 0; e < %d; ++e) {' % V)
-  L.append('      if (%s + e >= %d && %s + e < a.extent[0] - %d)' %
-           (_COORDS[0], lo[0], _COORDS[0], hi[0]))
+  cell_ok = ['%s + e >= %d' % (_COORDS[0], lo[0]),
+             '%s + e < a.extent[0] - %d' % (_COORDS[0], hi[0])]
+  cell_ok += [c.replace('+ %s ' % _COORDS[0], '+ %s + e ' % _COORDS[0])
+              for c in glob if 'origin[0]' in c]
+  L.append('      if (%s)' % ' && '.join(cell_ok))
   L.append('        soda_r[e] = (%s)(%s);' %
            (ct, ir.c_expr(stage.stmt.expr, scalar_load, mod.param_var)))
   L.append('    }')
@@ -224,6 +247,7 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
       lines.append('  %s soda_r = (%s)0;' % (ct, ct))
     else:   # border: preserve -- cells that are not computed keep the input
       lines.append('  %s soda_r = in_%s[soda_o];' % (ct, keep))
+      conds += _global_interior(st, stage, lambda d: _COORDS[d])
     lines.append('  if (%s) {' % (' && '.join(conds) if conds else 'true'))
 
     def load(ref: ir.Ref, _stage=stage) -> str:

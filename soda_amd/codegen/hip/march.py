@@ -545,7 +545,8 @@ class _MarchKernel:
       for o in self.st.output_names:
         wlo, whi = self.st.interior_bounds(o)
         for e in range(self.V):
-          self.w('  const bool keepx_%s_%d = !(x0 + %d >= %d && x0 + %d < n0 - %d);'
+          self.w('  const bool keepx_%s_%d = !(a.origin[0] + x0 + %d >= %d && '
+                 'a.origin[0] + x0 + %d < a.gextent[0] - %d);'
                  % (o, e, e, max(0, -wlo[0]), e, max(0, whi[0])))
     self.use_bperm = self.cfg.lane_shift == 'bperm'
     if self.use_bperm:
@@ -800,15 +801,17 @@ class _MarchKernel:
       wlo, whi = self.st.interior_bounds(stage.name)
       zero = (0,) * self.dim
       body.append('      {')
-      body.append('        const int mk = t - %d;' % n.delay)
-      body.append('        const bool keep_m = !(mk >= %d && mk < nm - %d);' %
-                  (max(0, -wlo[self.ax]), max(0, whi[self.ax])))
+      body.append('        const int mk = a.origin[%d] + t - %d;  // global plane'
+                  % (self.ax, n.delay))
+      body.append('        const bool keep_m = !(mk >= %d && mk < a.gextent[%d] - '
+                  '%d);' % (max(0, -wlo[self.ax]), self.ax,
+                            max(0, whi[self.ax])))
       for j in self.rows_of(n):
         keep_row = 'keep_m'
         if self.dim == 3:
-          body.append('        const bool keep_r%d = keep_m || !(y0 + %d >= %d '
-                      '&& y0 + %d < n1 - %d);' %
-                      (j, j, max(0, -wlo[1]), j, max(0, whi[1])))
+          body.append('        const bool keep_r%d = keep_m || !(a.origin[1] + '
+                      'y0 + %d >= %d && a.origin[1] + y0 + %d < a.gextent[1] - '
+                      '%d);' % (j, j, max(0, -wlo[1]), j, max(0, whi[1])))
           keep_row = 'keep_r%d' % j
         for e in range(self.V):
           dst = '%s_s%d_r%d[%d]' % (n.var, dst_slot, j, e)

@@ -317,6 +317,15 @@ static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
 int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,
                         int32_t iterate, void* stream_) {
+  return soda_hip_run_device_window(p, outputs, inputs, extent, nullptr,
+                                    nullptr, iterate, stream_);
+}
+
+int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
+                               const void* const* inputs,
+                               const int32_t* extent, const int32_t* origin,
+                               const int32_t* global_extent, int32_t iterate,
+                               void* stream_) {
   if (!p || !outputs || !inputs || !extent)
     return fail(SODA_HIP_ERR_INVALID, "run_device: NULL argument");
   const soda_hip_plan_t& plan = p->plan;
@@ -337,6 +346,11 @@ int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
     base.extent[d] = e;
     base.stride[d] = cells;
     cells *= e;
+    base.origin[d] = (origin && d < plan.dim) ? origin[d] : 0;
+    base.gextent[d] = (global_extent && d < plan.dim) ? global_extent[d] : e;
+    if (base.origin[d] < 0 || base.origin[d] + e > base.gextent[d])
+      return fail(SODA_HIP_ERR_INVALID,
+                  "run_device: the window does not lie in the global grid");
   }
   for (int i = 0; i < plan.num_inputs + plan.num_params; ++i)
     if (!inputs[i]) return fail(SODA_HIP_ERR_INVALID, "run_device: NULL input");

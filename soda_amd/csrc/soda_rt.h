@@ -34,6 +34,8 @@ struct soda_hip_kargs_t {
   int32_t extent[4];
   int32_t ntile[4];
   int32_t tile[4];
+  int32_t origin[4];
+  int32_t gextent[4];
 };
 
 #define SODA_DEV static __device__ inline __attribute__((always_inline))

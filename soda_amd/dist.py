@@ -35,10 +35,7 @@ class Slab:
       raise util.InputError('bad rank %d of %d' % (rank, world))
     if exchange_every < 1:
       raise util.InputError('exchange_every must be >= 1')
-    if stencil.preserve_border and world > 1:
-      raise util.SemanticError(
-          'border: preserve is not supported across slabs yet (the kernels '
-          'take the grid edge for the border)')
+
     self.stencil = stencil
     self.extent = tuple(extent)
     self.world = world
@@ -67,6 +64,13 @@ class Slab:
     self.row_cells = 1
     for e in self.extent[:-1]:
       self.row_cells *= e
+
+  @property
+  def origin(self) -> Tuple[int, ...]:
+    """Global position of cell 0 of this rank's arrays (what `border:
+    preserve` needs to tell the grid's border from a slab edge:
+    Program.run_device(..., origin=slab.origin, global_extent=slab.extent))."""
+    return (0,) * (len(self.extent) - 1) + (self.begin,)
 
   # neighbour traffic, in local row indices: (peer, send rows, recv rows)
   def messages(self) -> List[Tuple[int, Tuple[int, int], Tuple[int, int]]]:

@@ -97,6 +97,8 @@ API = {
     ]),
     'soda_hip_program_destroy': (ctypes.c_int, [_vp]),
     'soda_hip_run_device': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _i32, _vp]),
+    'soda_hip_run_device_window': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _pi32,
+                                                  _pi32, _i32, _vp]),
     'soda_hip_run_host': (ctypes.c_int, [
         _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32
     ]),
@@ -492,10 +494,13 @@ class Program:
   # -- device-resident arrays (the <app>_kernel analogue) ------------------
   def run_device(self, outputs: Sequence[int], inputs: Sequence[int],
                  extent: Sequence[int], iterate: Optional[int] = None,
-                 stream: int = 0) -> None:
+                 stream: int = 0, origin: Optional[Sequence[int]] = None,
+                 global_extent: Optional[Sequence[int]] = None) -> None:
     """`outputs` / `inputs` are device addresses (e.g. tensor.data_ptr()) of
     dense dim-0-fastest arrays; asynchronous on `stream`.  `inputs` holds the
-    input tensors followed by the program's `param` arrays (C order)."""
+    input tensors followed by the program's `param` arrays (C order).  For a
+    slab of a larger grid pass where its cell 0 sits (`origin`) and the size of
+    the whole grid (`global_extent`): `border: preserve` means the GLOBAL border."""
     st = self.stencil
     iterate = st.iterate if iterate is None else iterate
     self._check_extent(extent)
@@ -505,9 +510,12 @@ class Program:
     outs = (ctypes.c_void_p * len(outputs))(*outputs)
     ins = (ctypes.c_void_p * len(inputs))(*inputs)
     ext = (ctypes.c_int32 * len(extent))(*extent)
+    org = (ctypes.c_int32 * len(extent))(*(origin or [0] * len(extent)))
+    gext = (ctypes.c_int32 * len(extent))(*(global_extent or extent))
     check(
-        self._lib.soda_hip_run_device(self._handle, outs, ins, ext, iterate,
-                                      ctypes.c_void_p(stream)),
+        self._lib.soda_hip_run_device_window(self._handle, outs, ins, ext, org,
+                                             gext, iterate,
+                                             ctypes.c_void_p(stream)),
         'running `%s`' % st.app_name)
 
   def last_launches(self):

@@ -35,7 +35,8 @@ def test_struct_mirrors_match(built):
   from soda_amd import runtime
   lib = runtime.library()   # also runs the built-in layout check
   assert lib.soda_hip_abi_version() == runtime.ABI_VERSION
-  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 4 * 4 + 4 * 4 + 4 * 4
+  # buf, stride, extent, ntile, tile, origin, gextent
+  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 5 * 4 * 4
   assert lib.soda_hip_sizeof(3) == ctypes.sizeof(runtime.Plan)
   assert lib.soda_hip_sizeof(99) == 0
   assert lib.soda_hip_status_string(5) == b'no usable GPU'

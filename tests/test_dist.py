@@ -21,7 +21,8 @@ def _free_port():
   return port
 
 
-def _worker(rank, world, port, name, extent, iterate, every, out_dir):
+def _worker(rank, world, port, name, extent, iterate, every, out_dir,
+            border=None):
   import sys
   sys.path.insert(0, ROOT)
   sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -32,7 +33,7 @@ def _worker(rank, world, port, name, extent, iterate, every, out_dir):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   tdist.init_process_group('gloo', rank=rank, world_size=world)
-  stencil = core.from_file(soda_path(name), iterate=iterate)
+  stencil = core.from_file(soda_path(name), iterate=iterate, border=border)
   slab = sdist.Slab(stencil, extent, world, rank, every)
   rng = np.random.default_rng(42)
   full = {}
@@ -49,7 +50,8 @@ def _worker(rank, world, port, name, extent, iterate, every, out_dir):
 
   def step(dst, src, lext, iters):
     ins = {n: s.numpy() for n, s in zip(stencil.input_names, src)}
-    outs = numpy_oracle.run(stencil, ins, iterate=iters)
+    outs = numpy_oracle.run(stencil, ins, iterate=iters, origin=slab.origin,
+                            global_extent=slab.extent)
     for d, o in zip(dst, stencil.output_names):
       d.copy_(torch.from_numpy(outs[o]))
 
@@ -68,15 +70,20 @@ def _worker(rank, world, port, name, extent, iterate, every, out_dir):
     ('blur.soda', (40, 50), 3, 2, 2),      # one-sided halo (taps 0..2)
     ('skew2d.soda', (30, 40), 1, 1, 2),    # two-stage, asymmetric
 ])
+@pytest.mark.parametrize('border', [None, 'preserve'])
 def test_slabs_match_single_process(tmp_path, name, extent, iterate, every,
-                                    world):
+                                    world, border):
   import torch.multiprocessing as mp
-  from soda_amd import core
+  from soda_amd import core, util
   from oracle import numpy_oracle
+  stencil = core.from_file(soda_path(name), iterate=iterate, border=border)
+  try:
+    stencil.check_preserve()
+  except util.SemanticError:
+    pytest.skip('border: preserve does not apply to this program')
   port = _free_port()
   mp.spawn(_worker, args=(world, port, name, extent, iterate, every,
-                          str(tmp_path)), nprocs=world, join=True)
-  stencil = core.from_file(soda_path(name), iterate=iterate)
+                          str(tmp_path), border), nprocs=world, join=True)
   rng = np.random.default_rng(42)
   full = {}
   for n, t in zip(stencil.input_names, stencil.input_types):
@@ -206,7 +213,15 @@ def test_slab_geometry():
   assert (s.reach_lo, s.reach_hi, s.ghost_hi) == (0, 2, 6)
 
 
-def _gpu_worker(rank, world, port, name, extent, iterate, every, fuse, out_dir):
+def _full_inputs(stencil, extent, rng):
+  shape = tuple(extent[::-1])
+  return {n: (rng.random(shape, dtype=np.float32) if t.is_float else
+              rng.integers(0, 30000, shape).astype(t.np_name))
+          for n, t in zip(stencil.input_names, stencil.input_types)}
+
+
+def _gpu_worker(rank, world, port, name, extent, iterate, every, fuse, out_dir,
+                border=None, strategy='auto'):
   """Two ranks share the one GPU of the box; the halo exchange runs over gloo
   on host tensors, the K iterations between exchanges on the GPU kernels."""
   import sys
@@ -219,24 +234,25 @@ def _gpu_worker(rank, world, port, name, extent, iterate, every, fuse, out_dir):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   tdist.init_process_group('gloo', rank=rank, world_size=world)
-  stencil = core.from_file(soda_path(name), iterate=iterate)
+  stencil = core.from_file(soda_path(name), iterate=iterate, border=border)
   slab = sdist.Slab(stencil, extent, world, rank, every)
   rng = np.random.default_rng(7)
-  full = {n: rng.random(tuple(extent[::-1]), dtype=np.float32)
-          for n in stencil.input_names}
+  full = _full_inputs(stencil, extent, rng)
   src = [torch.from_numpy(full[n][slab.begin:slab.end].copy())
          for n in stencil.input_names]
   work_a = [torch.empty_like(t) for t in src]
   work_b = [torch.empty_like(t) for t in src]
-  prog = runtime.Program(stencil, lower.LowerOptions(fuse=fuse), device=0,
-                         extent=slab.local_extent)
+  prog = runtime.Program(stencil,
+                         lower.LowerOptions(fuse=fuse, strategy=strategy),
+                         device=0, extent=slab.local_extent)
 
   def step(dst, cur, lext, iters):
     d_in = [t.cuda() for t in cur]
     d_out = [torch.empty_like(t) for t in d_in]
     prog.run_device([t.data_ptr() for t in d_out],
                     [t.data_ptr() for t in d_in], lext, iterate=iters,
-                    stream=torch.cuda.current_stream().cuda_stream)
+                    stream=torch.cuda.current_stream().cuda_stream,
+                    origin=slab.origin, global_extent=slab.extent)
     torch.cuda.synchronize()
     for h, d in zip(dst, d_out):
       h.copy_(d.cpu())
@@ -250,11 +266,17 @@ def _gpu_worker(rank, world, port, name, extent, iterate, every, fuse, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,extent,iterate,every,fuse', [
-    ('jacobi2d.soda', (1000, 400), 14, 6, (3,)),   # 3 exchange rounds
-    ('heat3d.soda', (260, 24, 60), 5, 2, ()),
+@pytest.mark.parametrize('name,extent,iterate,every,fuse,border,strategy', [
+    ('jacobi2d.soda', (1000, 400), 14, 6, (3,), None, 'auto'),  # 3 rounds
+    ('heat3d.soda', (260, 24, 60), 5, 2, (), None, 'auto'),
+    # border: preserve -- the kernels must tell the grid's border (kept) from
+    # the seam between the slabs (computed)
+    ('jacobi2d.soda', (1000, 400), 14, 6, (3,), 'preserve', 'auto'),
+    ('heat3d.soda', (260, 24, 60), 6, 2, (2,), 'preserve', 'auto'),
+    ('seidel2d.soda', (640, 300), 4, 2, (), 'preserve', 'direct'),
 ])
-def test_two_ranks_on_gpu_kernels(tmp_path, name, extent, iterate, every, fuse):
+def test_two_ranks_on_gpu_kernels(tmp_path, name, extent, iterate, every, fuse,
+                                  border, strategy):
   """The GPU engine inside the slab/exchange loop (exchanges really happen:
   K < iterate), against the single-process oracle on the global valid box."""
   import torch.multiprocessing as mp
@@ -263,11 +285,11 @@ def test_two_ranks_on_gpu_kernels(tmp_path, name, extent, iterate, every, fuse):
   world = 2
   port = _free_port()
   mp.spawn(_gpu_worker, args=(world, port, name, extent, iterate, every, fuse,
-                              str(tmp_path)), nprocs=world, join=True)
-  stencil = core.from_file(soda_path(name), iterate=iterate)
+                              str(tmp_path), border, strategy), nprocs=world,
+           join=True)
+  stencil = core.from_file(soda_path(name), iterate=iterate, border=border)
   rng = np.random.default_rng(7)
-  full = {n: rng.random(tuple(extent[::-1]), dtype=np.float32)
-          for n in stencil.input_names}
+  full = _full_inputs(stencil, extent, rng)
   want = c_oracle.COracle(stencil).run(full)[stencil.output_names[0]]
   got = np.concatenate([np.load(os.path.join(str(tmp_path), 'rank%d.npy' % r))
                         for r in range(world)], axis=0)
