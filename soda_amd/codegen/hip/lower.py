@@ -70,7 +70,11 @@ class LowerOptions:
                warm_guards: bool = False, interleave: bool = False,
                lane_shift: str = 'dpp', min_waves: int = 0,
                occupancy: int = 0, buffer_ops: bool = True,
-               pipe: Optional[int] = None, pipe_rows: int = 2):
+               pipe: Optional[int] = None, pipe_rows: int = 2,
+               reg_budget: Optional[int] = None):
+    # estimated VGPRs a marching shape may need before the ladder in lower()
+    # moves on to a leaner one (None: REG_BUDGET)
+    self.reg_budget = reg_budget
     # waves of a block sharing the fused iterations of a 2-D kernel; None =
     # default_pipe(fusion depth)
     self.pipe = pipe
@@ -105,7 +109,7 @@ class LowerOptions:
                        self.edge_loads, self.tile_rows, self.warm_guards,
                        self.interleave, self.lane_shift, self.min_waves,
                        self.occupancy, self.buffer_ops, self.pipe,
-                       self.pipe_rows)
+                       self.pipe_rows, self.reg_budget)
     if out.prefetch is None and dim == 3:
       out.prefetch = 1
     # 2-D: resolved per fusion depth in lower() (default_prefetch)
@@ -198,11 +202,13 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
             opts.buffer_ops and opts.waves_x * opts.waves_y == 1)
       return want if ok else 1
 
-    def config(t: int, vec: int, pf: int) -> MarchConfig:
+    def config(t: int, vec: int, pf: int, rows: Optional[int] = None
+               ) -> MarchConfig:
       cfg = MarchConfig(t, vec, opts.chunk_rows or 64, pf,
                         opts.waves_x, opts.waves_y, opts.nt_store,
                         opts.nt_load, opts.xcd_swizzle, opts.edge_loads,
-                        opts.tile_rows, opts.warm_guards, opts.interleave,
+                        rows or opts.tile_rows, opts.warm_guards,
+                        opts.interleave,
                         opts.lane_shift, opts.min_waves, opts.occupancy,
                         opts.buffer_ops,
                         pipe_for(t), opts.pipe_rows)
@@ -212,11 +218,16 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     # The one-iteration kernel is mandatory.  Tall windows (erosion and xcorr
     # read 19 rows) or many live tensors may not fit the register budget at
     # the preferred shape: try shallower prefetch, then fewer cells per lane,
-    # and take the first shape whose estimate stays within REG_BUDGET (else
-    # the leanest); only if none exists fall back to `direct` kernels.
+    # and take the first shape whose estimate stays
+    # within the register budget (else the leanest); only if none exists fall
+    # back to `direct` kernels.
+    budget = opts.reg_budget or REG_BUDGET
     pfs = [opts.prefetch] if opts.prefetch else [
         default_prefetch(1) if stencil.dim == 2 else 1, 2, 1]
     pfs = sorted(set(pfs), reverse=True)
+    # (3-D: fewer rows per tile never paid -- denoise3d 512^3: 651 / 691 / 910
+    # us at 4 / 2 / 1 rows, 1 cell per lane -- so the tile height stays)
+    rows_list = [opts.tile_rows]
     vecs = []
     v = vec0
     while v >= 1:
@@ -225,26 +236,29 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     chosen = None
     last_error = None
     for v in vecs:
-      for pf in pfs:
-        trial = Module(stencil)
-        try:
-          est = add_march_pass(trial, config(1, v, pf)).traffic_model[
-              'est_window_regs']
-        except util.SemanticError as e:
-          last_error = e
-          continue
-        if chosen is None or est < chosen[0]:
-          chosen = (est, v, pf)
-        if est <= REG_BUDGET:
+      for rows in rows_list:
+        for pf in pfs:
+          trial = Module(stencil)
+          try:
+            est = add_march_pass(trial, config(1, v, pf, rows)).traffic_model[
+                'est_window_regs']
+          except util.SemanticError as e:
+            last_error = e
+            continue
+          if chosen is None or est < chosen[0]:
+            chosen = (est, v, pf, rows)
+          if est <= budget:
+            break
+        if chosen and chosen[0] <= budget:
           break
-      if chosen and chosen[0] <= REG_BUDGET:
+      if chosen and chosen[0] <= budget:
         break
     if chosen is None:
       if opts.strategy == 'march':
         raise last_error
       use_march = False
     else:
-      _, vec, pf1 = chosen
+      _, vec, pf1, rows1 = chosen
       for t in depths:
         keep = (len(mod.kernels), len(mod.passes), len(mod.chunks))
         try:
@@ -253,7 +267,7 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
         except util.SemanticError:
           # this depth does not fit; the scheduler uses the others
           del mod.kernels[keep[0]:], mod.passes[keep[1]:], mod.chunks[keep[2]:]
-      add_march_pass(mod, config(1, vec, pf1))
+      add_march_pass(mod, config(1, vec, pf1, rows1))
   if not use_march:
     add_direct_pass(mod, opts.vec or 1)
   return mod

@@ -353,8 +353,40 @@ class _MarchKernel:
           (max(n.window for n in self.nodes), MAX_UNROLL))
     for n in self.nodes:
       n.slots = min(d for d in range(1, self.U + 1) if self.U % d == 0 and d >= n.window)
+    # rows (3-D) of every tensor that some output row of the tile depends on:
+    # the generator emits all rows a tensor can hold, the compiler drops the
+    # statements nobody reads -- the estimate must not count them (denoise3d:
+    # 10 stages, most of them needed on the 2-4 output rows only)
+    need = {id(n): None for n in self.nodes}
+    for n in self.out_nodes:
+      need[id(n)] = (self.rhalo_lo, self.rows_in - self.rhalo_hi)
+    for n in reversed(self.nodes):
+      if need[id(n)] is None:
+        continue
+      src = n.mirror_of
+      if src is not None:
+        need[id(src)] = need[id(n)]
+        continue
+      if n.stage is None:
+        continue
+      a, b = need[id(n)]
+      for pname, pnode in n.parents.items():
+        tlo, thi = n.tap_bounds(pname)
+        lo = a + (tlo[1] if self.dim == 3 else 0)
+        hi = b + (thi[1] if self.dim == 3 else 0)
+        cur = need[id(pnode)]
+        need[id(pnode)] = (lo, hi) if cur is None else (min(cur[0], lo),
+                                                         max(cur[1], hi))
+
+    def rows_needed(n: _Node) -> int:
+      if need[id(n)] is None:
+        return 0
+      lo = max(need[id(n)][0], n.rmargin[0])
+      hi = min(need[id(n)][1], self.rows_in - n.rmargin[1])
+      return max(0, hi - lo)
+
     self.est_regs = max(
-        sum(n.slots * self.V * max(0, self.rows_in - n.rmargin[0] - n.rmargin[1])
+        sum(n.slots * self.V * rows_needed(n)
             for n in self.nodes if n.owner == wv) for wv in range(self.W))
     if self.est_regs > 400:
       raise util.SemanticError(

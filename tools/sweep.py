@@ -35,6 +35,7 @@ def main():
   ap.add_argument('--buf', type=int, nargs='+', default=[1])
   ap.add_argument('--pipe', type=int, nargs='+', default=[1])
   ap.add_argument('--pipe-rows', type=int, nargs='+', default=[4])
+  ap.add_argument('--reg-budget', type=int, default=None)
   ap.add_argument('--rounds', type=int, default=3)
   ap.add_argument('--reps', type=int, default=20)
   ap.add_argument('--launches', type=int, default=1, help='launches per call (ping-pong through the program temporaries, as in a real run)')
@@ -58,7 +59,7 @@ def main():
                               prefetch=pf, waves_x=wx, waves_y=wy,
                               nt_store=bool(nts), nt_load=bool(ntl),
                               xcd_swizzle=bool(xcd), vec=vec if vec > 0 else None,
-                              tile_rows=trows, edge_loads=bool(edge), warm_guards=bool(wg), interleave=bool(il), lane_shift=shift, min_waves=mw, occupancy=occ, buffer_ops=bool(buf), pipe=pipe, pipe_rows=prow)
+                              tile_rows=trows, edge_loads=bool(edge), warm_guards=bool(wg), interleave=bool(il), lane_shift=shift, min_waves=mw, occupancy=occ, buffer_ops=bool(buf), pipe=pipe, pipe_rows=prow, reg_budget=args.reg_budget)
     try:
       progs.append((runtime.Program(st, opts, extent=args.extent), st, fuse))
     except Exception as e:  # noqa
