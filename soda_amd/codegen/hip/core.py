@@ -7,6 +7,8 @@ opencl.py:55-142).  This module slots into the same place:
 
   --hip-kernel FILE   print the generated HIP source ('-' = stdout), the
                       counterpart of --xocl-kernel;
+  --hip-host FILE     print the C++ host: soda::app::<app>() with the reference's
+                      --frt-host signature, on libsoda_hip.so (host.py);
   --hip-backend       JIT-build the kernels for gfx950 and RUN the program on
                       the GPU with the reference harness's inputs, checking
                       nothing by itself (the oracle lives in tests/); prints
@@ -26,6 +28,9 @@ from soda_amd.codegen.hip import lower
 def add_arguments(parser) -> None:
   parser.add_argument('--hip-kernel', type=str, dest='hip_kernel',
                       metavar='file', help='HIP kernel code for gfx950')
+  parser.add_argument('--hip-host', type=str, dest='hip_host', metavar='file',
+                      help='C++ host: soda::app::<app>() with the signature '
+                      'of --frt-host, on libsoda_hip.so')
   parser.add_argument('--hip-backend', action='store_true', dest='hip_backend',
                       help='JIT-build the HIP kernels and run them on the GPU')
   parser.add_argument('--hip-strategy', type=str, dest='hip_strategy',
@@ -94,6 +99,14 @@ def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
       else:
         with open(args.hip_kernel, 'w') as f:
           shutil.copyfileobj(tmp, f)
+  if getattr(args, 'hip_host', None) is not None:
+    from soda_amd.codegen.hip import host
+    text = host.print_host(stencil, options_from_args(args), args.hip_extent)
+    if args.hip_host == '-':
+      sys.stdout.write(text)
+    else:
+      with open(args.hip_host, 'w') as f:
+        f.write(text)
   if args.hip_backend:
     run(stencil, args)
 
