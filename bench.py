@@ -152,7 +152,19 @@ def main():
   if args.scaling == 'weak' and world > 1:
     extent[-1] *= world
   fuses = sorted({f for f in args.fuse if f >= 1}, reverse=True)
-  fuse = fuses[0]
+
+  def options(fuse_list):
+    return lower.LowerOptions(strategy=args.strategy,
+                              fuse=tuple(f for f in fuse_list if f > 1),
+                              chunk_rows=args.chunk_rows,
+                              prefetch=args.prefetch, waves_x=args.waves_x,
+                              waves_y=args.waves_y, pipe=args.pipe)
+
+  # the depth the lowering really fuses (3-D programs cap it, a program that
+  # cannot iterate has none): a dry lowering tells, no GPU needed
+  dry = options(fuses)
+  dry.vec = runtime.pick_vec(stencil, extent)
+  fuse = lower.lower(stencil, dry).sorted_passes()[0].fused_iters
   geo_world, geo_rank = (emulate, emulate // 2) if emulate > 1 else (world, rank)
   if geo_world == 1:
     ex = args.iterate
@@ -169,13 +181,6 @@ def main():
       raise SystemExit('--emulate-slab needs an exchange-free schedule')
     slab.world = 1   # no peers: exchange() is a no-op
   local_extent = slab.local_extent
-
-  def options(fuse_list):
-    return lower.LowerOptions(strategy=args.strategy,
-                              fuse=tuple(f for f in fuse_list if f > 1),
-                              chunk_rows=args.chunk_rows,
-                              prefetch=args.prefetch, waves_x=args.waves_x,
-                              waves_y=args.waves_y, pipe=args.pipe)
 
   prog = runtime.Program(stencil, options(fuses), device=local_rank,
                          extent=local_extent)
