@@ -101,6 +101,9 @@ typedef struct soda_hip_pass_desc {
   int32_t fused_iters;
   int32_t num_kernels;
   int32_t kernel[SODA_HIP_MAX_PASS_KERNELS];
+  float cost;                          /* relative time of one such pass (any
+                                          unit); <= 0 in every pass: schedule
+                                          greedily, deepest first */
 } soda_hip_pass_desc_t;
 
 typedef struct soda_hip_plan {
@@ -120,7 +123,10 @@ typedef struct soda_hip_plan {
   soda_hip_kernel_desc_t kernels[SODA_HIP_MAX_KERNELS];
   int32_t num_passes;                  /* sorted by fused_iters, largest first;
                                           the last one must have fused_iters 1
-                                          when the program iterates */
+                                          when the program iterates.  A run of
+                                          N iterations uses the multiset of
+                                          passes of least total cost that adds
+                                          up to N, deepest first */
   soda_hip_pass_desc_t passes[SODA_HIP_MAX_PASSES];
 } soda_hip_plan_t;
 

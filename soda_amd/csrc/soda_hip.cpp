@@ -314,6 +314,46 @@ static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
   return SODA_HIP_OK;
 }
 
+static int schedule(const soda_hip_plan_t& plan, int32_t iterate,
+                    int32_t* count, int32_t* total) {
+  bool costed = false;
+  for (int i = 0; i < plan.num_passes; ++i)
+    costed = costed || plan.passes[i].cost > 0.f;
+  *total = 0;
+  if (!costed || iterate > (1 << 20)) {      // greedy, deepest first
+    int32_t remaining = iterate;
+    for (int i = 0; i < plan.num_passes; ++i) {
+      count[i] = remaining / plan.passes[i].fused_iters;
+      remaining -= count[i] * plan.passes[i].fused_iters;
+      *total += count[i];
+    }
+    return remaining ? fail(SODA_HIP_ERR_INVALID, "iterate not schedulable")
+                     : SODA_HIP_OK;
+  }
+  // unbounded knapsack over the iteration count: best[n] = least cost of n
+  // iterations, pick[n] = the pass used last
+  std::vector<double> best(iterate + 1, 1e300);
+  std::vector<int8_t> pick(iterate + 1, -1);
+  best[0] = 0.0;
+  for (int32_t n = 1; n <= iterate; ++n)
+    for (int i = 0; i < plan.num_passes; ++i) {
+      const int32_t t = plan.passes[i].fused_iters;
+      const double c = plan.passes[i].cost > 0.f ? plan.passes[i].cost : 1e6;
+      if (t <= n && best[n - t] < 1e299 && best[n - t] + c < best[n]) {
+        best[n] = best[n - t] + c;
+        pick[n] = (int8_t)i;
+      }
+    }
+  if (pick[iterate] < 0)
+    return fail(SODA_HIP_ERR_INVALID, "iterate not schedulable");
+  for (int i = 0; i < plan.num_passes; ++i) count[i] = 0;
+  for (int32_t n = iterate; n > 0; n -= plan.passes[pick[n]].fused_iters) {
+    ++count[pick[n]];
+    ++*total;
+  }
+  return SODA_HIP_OK;
+}
+
 int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,
                         int32_t iterate, void* stream_) {
@@ -363,15 +403,13 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
                     "run_device: an output aliases an input (in-place runs are "
                     "not supported: inputs are read while outputs are written)");
 
-  // schedule: as many passes of the most-fused kind as fit, then the next...
+  // schedule: the multiset of passes that adds up to `iterate` at least total
+  // cost (100 iterations with passes of 12 / 8 / 4 / 1: 7 x 12 + 2 x 8 beats
+  // 8 x 12 + 4); without costs, as many of the deepest kind as fit, then the
+  // next...
   int32_t count[SODA_HIP_MAX_PASSES];
-  int32_t remaining = iterate, total = 0;
-  for (int i = 0; i < plan.num_passes; ++i) {
-    count[i] = remaining / plan.passes[i].fused_iters;
-    remaining -= count[i] * plan.passes[i].fused_iters;
-    total += count[i];
-  }
-  if (remaining) return fail(SODA_HIP_ERR_INVALID, "iterate not schedulable");
+  int32_t total = 0;
+  if (int rc = schedule(plan, iterate, count, &total)) return rc;
 
   const int in0 = 0, out0 = plan.num_inputs, loc0 = out0 + plan.num_outputs;
   const int prm0 = loc0 + plan.num_locals;

@@ -53,7 +53,8 @@ class KernelDesc(ctypes.Structure):
 class PassDesc(ctypes.Structure):
   _fields_ = [('fused_iters', ctypes.c_int32),
               ('num_kernels', ctypes.c_int32),
-              ('kernel', ctypes.c_int32 * MAX_PASS_KERNELS)]
+              ('kernel', ctypes.c_int32 * MAX_PASS_KERNELS),
+              ('cost', ctypes.c_float)]
 
 
 class Plan(ctypes.Structure):
@@ -220,6 +221,16 @@ def compile_source(source: str, name: str = 'soda.hip',
   return blob
 
 
+def pass_cost(fused_iters: int) -> float:
+  """Relative time of one pass that fuses T iterations, for the scheduler in
+  soda_hip_run_device: a memory floor that rises slowly with T (more halo) or,
+  from T ~ 9, the VALU time.  Fitted to jacobi2d 8192^2 (90 / 104 / 117 / 154 us
+  at T = 1 / 4 / 8 / 12); only ratios matter, and only when several depths are
+  available (100 iterations with 12 / 8 / 4: 7 x 12 + 2 x 8, not 8 x 12 + 4)."""
+  t = float(fused_iters)
+  return max(1.0 + 0.04 * t, 0.1425 * t)
+
+
 def make_plan(mod: lower.Module) -> Plan:
   st = mod.stencil
   plan = Plan()
@@ -260,6 +271,7 @@ def make_plan(mod: lower.Module) -> Plan:
           'a pass of %d kernels exceeds the limit of %d' %
           (len(p.kernels), MAX_PASS_KERNELS))
     plan.passes[i].num_kernels = len(p.kernels)
+    plan.passes[i].cost = pass_cost(p.fused_iters)
     for j, k in enumerate(p.kernels):
       plan.passes[i].kernel[j] = k
   return plan

@@ -543,3 +543,27 @@ def test_param_arrays(built, text, extent, opts):
   bordered = (core.from_text(text, border='preserve') if text else
               core.from_file(soda_path('conv2d.soda'), border='preserve'))
   _check(bordered, extent, lower.LowerOptions(**opts))
+
+
+def test_scheduler_picks_the_cheapest_pass_mix(built):
+  """100 iterations with kernels of 12 / 8 / 4 / 1 fused iterations run as
+  7 x 12 + 2 x 8 (the library's cost-aware schedule), not 8 x 12 + 4, and the
+  result is the same bits either way."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  import torch
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=100)
+  extent = (1024, 600)
+  a = torch.rand((600, 1024), device='cuda')
+  outs = []
+  for fuse in ((12, 8, 4), (12, 4)):
+    b = torch.empty_like(a)
+    with runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
+                         extent=extent) as prog:
+      prog.run_device([b.data_ptr()], [a.data_ptr()], extent)
+      torch.cuda.synchronize()
+      launches, deepest = prog.last_launches()
+      assert launches == 9
+      assert deepest == (7 if 8 in fuse else 8)
+    outs.append(b[100:500, 100:924].clone())
+  assert torch.equal(outs[0], outs[1])
