@@ -69,6 +69,26 @@ def main():
                         **{'in_' + k: v for k, v in ins.items()},
                         **{'out_' + k: v for k, v in outs.items()})
 
+  # features the reference declares but never delivered, as defined by this
+  # build: `border: preserve` and `param` arrays.  Own
+  # seed, so the vectors above never move.
+  rng2 = np.random.default_rng(20260102)
+  for tag, name, kw, shape in (
+      ('jacobi2d_preserve', 'jacobi2d', dict(iterate=3, border='preserve'),
+       (20, 36)),
+      ('heat3d_preserve', 'heat3d', dict(iterate=2, border='preserve'),
+       (10, 12, 16)),
+      ('conv2d', '../conv2d', dict(), (20, 36)),
+      ('conv2d_preserve', '../conv2d', dict(border='preserve'), (20, 36))):
+    st = core.from_file(os.path.join(HERE, 'soda', name + '.soda'), **kw)
+    ins = {n: rng2.random(shape, dtype=np.float32) for n in st.input_names}
+    for p in st.param_stmts:
+      ins[p.name] = rng2.random(p.size or (1,)).astype(p.haoda_type.np_name)
+    outs = numpy_oracle.run(st, ins)
+    np.savez_compressed(os.path.join(HERE, tag + '.npz'), iterate=st.iterate,
+                        **{'in_' + k: v for k, v in ins.items()},
+                        **{'out_' + k: v for k, v in outs.items()})
+
 
 if __name__ == '__main__':
   main()

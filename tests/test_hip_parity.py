@@ -567,3 +567,35 @@ def test_scheduler_picks_the_cheapest_pass_mix(built):
       assert deepest == (7 if 8 in fuse else 8)
     outs.append(b[100:500, 100:924].clone())
   assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('tag,soda,border', [
+    ('jacobi2d', 'jacobi2d.soda', None),       # hand-written C kernels' outputs
+    ('blur', 'blur.soda', None),
+    ('heat3d', 'heat3d.soda', None),
+    ('skew2d', 'skew2d.soda', None),
+    ('sobel2d', 'sobel2d.soda', None),
+    ('denoise2d', 'denoise2d.soda', None),
+    ('jacobi2d_preserve', 'jacobi2d.soda', 'preserve'),
+    ('heat3d_preserve', 'heat3d.soda', 'preserve'),
+    ('conv2d', 'conv2d.soda', None),
+    ('conv2d_preserve', 'conv2d.soda', 'preserve')])
+@pytest.mark.parametrize('strategy', ['auto', 'direct'])
+def test_committed_golden_vectors_on_gpu(built, tag, soda, border, strategy):
+  """The committed vectors (tests/golden/make_golden.py) through the kernels."""
+  import os
+  from conftest import GOLDEN_DIR
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  data = np.load(os.path.join(GOLDEN_DIR, '%s.npz' % tag))
+  st = core.from_file(soda_path(soda), iterate=int(data['iterate']),
+                      border=border)
+  ins = {n: data['in_' + n] for n in st.input_names + st.param_names}
+  extent = tuple(ins[st.input_names[0]].shape[::-1])
+  with runtime.Program(st, lower.LowerOptions(strategy=strategy, fuse=(2,)),
+                       extent=extent) as prog:
+    got = prog.run(ins)
+  for o in st.output_names:
+    lo, hi = st.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(got[o][idx], data['out_' + o][idx])

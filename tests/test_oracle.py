@@ -186,6 +186,27 @@ def test_committed_golden_vectors(name):
     assert np.array_equal(got[o], data['out_' + o])
 
 
+GOLDEN_EXTRA = [('jacobi2d_preserve', 'jacobi2d.soda', 'preserve'),
+                ('heat3d_preserve', 'heat3d.soda', 'preserve'),
+                ('conv2d', 'conv2d.soda', None),
+                ('conv2d_preserve', 'conv2d.soda', 'preserve')]
+
+
+@pytest.mark.parametrize('tag,soda,border', GOLDEN_EXTRA)
+def test_committed_golden_vectors_preserve_and_params(tag, soda, border):
+  """`border: preserve` and `param` arrays as this build defines them
+  (DESIGN.md 4.5, 4.6), frozen; both oracles reproduce them."""
+  from oracle import c_oracle, numpy_oracle
+  data = np.load(os.path.join(GOLDEN_DIR, '%s.npz' % tag))
+  st = core.from_file(soda_path(soda), iterate=int(data['iterate']),
+                      border=border)
+  ins = {n: data['in_' + n] for n in st.input_names + st.param_names}
+  for run in (numpy_oracle.run, c_oracle.COracle(st, openmp=False).run):
+    got = run(st, ins) if run is numpy_oracle.run else run(ins)
+    for o in st.output_names:
+      assert np.array_equal(got[o], data['out_' + o])
+
+
 @pytest.mark.parametrize('name', ['coupled2d.soda', 'lets2d.soda',
                                   'ints2d.soda'])
 def test_language_surface_numpy_vs_generated_c(name):
