@@ -599,3 +599,23 @@ def test_committed_golden_vectors_on_gpu(built, tag, soda, border, strategy):
     lo, hi = st.valid_box(extent, o)
     idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
     assert np.array_equal(got[o][idx], data['out_' + o][idx])
+
+
+@pytest.mark.parametrize('name,iterate,opts,extent,border', [
+    ('jacobi2d.soda', 24, dict(fuse=(12,)), (2050, 1031), None),   # V=2 rows
+    ('jacobi2d.soda', 24, dict(fuse=(12,), pipe=4), (2052, 1031), None),
+    ('jacobi2d.soda', 13, dict(fuse=(12, 4)), (1027, 517), None),  # V=1 rows
+    ('jacobi2d.soda', 9, dict(fuse=(8,)), (1027, 517), 'preserve'),
+    ('blur.soda', 1, dict(), (4100, 2057), None),                  # u16, V=4
+    ('heat3d.soda', 6, dict(fuse=(2,)), (258, 131, 70), None),
+    ('heat3d.soda', 5, dict(fuse=(2,)), (130, 70, 33), 'preserve'),
+    ('denoise2d.soda', 1, dict(), (1026, 519), None),
+])
+def test_awkward_mid_size_grids(built, name, iterate, opts, extent, border):
+  """Row lengths that force narrower vectors, ragged last strips / chunks /
+  tiles, at sizes where every strip-chunk combination occurs; against the
+  OpenMP C oracle."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate, border=border)
+  _check(stencil, extent, lower.LowerOptions(**opts), oracle='c')
