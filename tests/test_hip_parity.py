@@ -619,3 +619,46 @@ def test_awkward_mid_size_grids(built, name, iterate, opts, extent, border):
   from soda_amd.codegen.hip import lower
   stencil = core.from_file(soda_path(name), iterate=iterate, border=border)
   _check(stencil, extent, lower.LowerOptions(**opts), oracle='c')
+
+
+@pytest.mark.parametrize('name,extent,iterate,fuse,strategy', [
+    ('jacobi2d.soda', (32768, 32768), 4, (4,), 'auto'),
+    ('jacobi2d.soda', (32768, 32768), 2, (), 'direct'),
+    ('heat3d.soda', (1024, 1024, 1024), 2, (2,), 'auto'),
+])
+def test_beyond_4gib_arrays(built, name, extent, iterate, fuse, strategy):
+  """4 GiB per array: byte offsets past 2^32, where the 32-bit buffer offsets
+  of the marching kernels rely on the per-wave window rebasing and the direct
+  kernels on 64-bit indices.  Device-resident; the fused and the
+  one-iteration-per-launch schedules must agree bit for bit over the whole
+  array, and three slabs along the last dimension (start, across 2 GiB, end)
+  must equal the CPU oracle run on just those slabs."""
+  import torch
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import numpy_oracle
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  shape = tuple(extent[::-1])
+  a = torch.rand(shape, device='cuda')
+  outs = []
+  for f in ((fuse, ()) if fuse else ((),)):
+    b = torch.empty_like(a)
+    with runtime.Program(stencil, lower.LowerOptions(fuse=f, strategy=strategy),
+                         extent=extent) as prog:
+      prog.run_device([b.data_ptr()], [a.data_ptr()], extent)
+      torch.cuda.synchronize()
+    outs.append(b)
+  r = iterate                       # cells the border eats per side
+  inner = tuple(slice(r, -r) for _ in extent)
+  if len(outs) == 2:
+    assert torch.equal(outs[0][inner], outs[1][inner])
+  n_last = extent[-1]
+  thick = 48 if len(extent) == 2 else 12
+  for start in (0, n_last // 2 - thick // 2, n_last - thick):
+    sl = slice(start, start + thick)
+    part = {stencil.input_names[0]: a[sl].cpu().numpy()}
+    want = numpy_oracle.run(stencil, part)[stencil.output_names[0]]
+    got = outs[0][sl].cpu().numpy()
+    assert np.array_equal(got[inner], want[inner]), start
+  del outs, a
+  torch.cuda.empty_cache()
