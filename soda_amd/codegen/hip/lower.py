@@ -198,8 +198,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
 
     def pipe_for(t: int) -> int:
       want = default_pipe(t) if opts.pipe is None else opts.pipe
-      ok = (want > 1 and t > 1 and t % want == 0 and stencil.dim == 2 and
-            opts.buffer_ops and opts.waves_x * opts.waves_y == 1)
+      ok = (want > 1 and t > 1 and t % want == 0 and opts.buffer_ops and
+            opts.waves_x * opts.waves_y == 1)
       return want if ok else 1
 
     def config(t: int, vec: int, pf: int, rows: Optional[int] = None

@@ -307,11 +307,11 @@ class _MarchKernel:
         self.edge = (lo, hi)
     self.W = self.cfg.pipe
     if self.W > 1:
-      if self.dim != 2 or self.T % self.W or not self.cfg.buffer_ops or \
+      if self.T % self.W or not self.cfg.buffer_ops or \
           self.cfg.waves_x * self.cfg.waves_y != 1:
         raise util.SemanticError(
-            'march: %d pipelined waves need a 2-D program, a fusion depth that '
-            'is a multiple of it, buffer addressing and one strip per block' % self.W)
+            'march: %d pipelined waves need a fusion depth that is a multiple '
+            'of it, buffer addressing and one strip per block' % self.W)
       self.edge = (0, 0)
     self.R = self.cfg.pipe_rows if self.W > 1 else 1
     if self.R & (self.R - 1):
@@ -592,8 +592,8 @@ class _MarchKernel:
           self.w(line)
     for n in self.nodes:
       if n.to_lds:     # written at tick t, read by the next wave at tick t + R
-        self.w('  __shared__ %s soda_ring_%s[%d][%d];' % (n.ctype, n.var, 2 * self.R,
-                                                   64 * self.V))
+        self.w('  __shared__ %s soda_ring_%s[%d][%d][%d];' % (
+            n.ctype, n.var, 2 * self.R, self.rows_in, 64 * self.V))
     if not self.buf:
       self.w('  const int in_end = min(nm, m_end + %d);  // last input plane needed + 1'
         % self.m_hi)
@@ -693,10 +693,11 @@ class _MarchKernel:
     for n in self.nodes:
       if n.mirror_of is not None and n.owner == wv:
         # the plane the previous wave wrote R ticks (one barrier) ago
-        self.w('      soda_load_frag<%s, %d, false>(%s_s%d_r0, &soda_ring_%s'
-          '[(t + %d) & %d][lane * %d]);' %
-          (n.ctype, self.V, n.var, self.slot_of(n, k, 0), n.mirror_of.var, self.R, 2 * self.R - 1,
-           self.V))
+        for j in self.rows_of(n):
+          self.w('      soda_load_frag<%s, %d, false>(%s_s%d_r%d, &soda_ring_%s'
+                 '[(t + %d) & %d][%d][lane * %d]);' %
+                 (n.ctype, self.V, n.var, self.slot_of(n, k, 0), j,
+                  n.mirror_of.var, self.R, 2 * self.R - 1, j, self.V))
     # 2. compute every tensor's new plane
     self._shifted: Dict[Tuple[str, int, int, int, int], str] = {}
     self._stage_mark = len(self.L)
@@ -858,9 +859,11 @@ class _MarchKernel:
       self.w('      }')
       self._shifted = {}
     if n.to_lds:   # hand the new plane to the next wave of the block
-      self.w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][lane * '
-        '%d], %s_s%d_r0);' % (n.ctype, self.V, n.var, 2 * self.R - 1, self.V, n.var,
-                              dst_slot))
+      for j in self.rows_of(n):
+        self.w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][%d]'
+               '[lane * %d], %s_s%d_r%d);' %
+               (n.ctype, self.V, n.var, 2 * self.R - 1, j, self.V, n.var,
+                dst_slot, j))
     if n.store_slot is not None:
       self._emit_store(n, stage.name, dst_slot)
 

@@ -460,6 +460,8 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
     ('blur.soda', 6, 6, 3, (1024, 50)),
     ('coupled2d.soda', 4, 4, 2, (300, 90)),          # 2 tensors cross per wave
     ('coupled2d.soda', 6, 6, 3, (300, 90)),
+    ('heat3d.soda', 6, 2, 2, (300, 24, 40)),         # 3-D: tile planes handed on
+    ('jacobi3d.soda', 4, 2, 2, (64, 21, 33)),
 ])
 def test_stage_pipelined_blocks(built, name, iterate, fuse, pipe, extent):
   """The fused iterations split over the waves of a block (rows handed from
