@@ -87,6 +87,12 @@ def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
 
 
 def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
+  if not isinstance(stencil, core.Stencil):
+    # called from the reference's own driver with ITS Stencil (expression tree
+    # in the un-vendored haoda): both print the same DSL normal form
+    # (reference src/soda/core.py:157-166, src/tests/test_grammar.py:24-61), so
+    # re-read it
+    stencil = core.from_text(str(stencil))
   if args.hip_kernel is not None:
     opts = options_from_args(args)
     if opts.vec is None:

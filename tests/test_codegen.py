@@ -275,3 +275,29 @@ def test_march_loop_body_is_branch_free():
       'input float: a(32, *)\noutput float: b(0, 0) = a(0, 1) + a(0, -1)\n'
       'output float: c(0, 0) = 38\n')
   assert '// prologue' not in lower.lower(const, lower.LowerOptions(fuse=())).source
+
+
+def test_print_code_accepts_a_foreign_stencil_object(tmp_path):
+  """The plug-in called from the reference's driver gets the reference's
+  Stencil (a different class, haoda expression tree): anything that prints the
+  DSL normal form works."""
+  import argparse
+  from soda_amd.codegen.hip import core as hip
+
+  class Foreign:                      # stands for reference core.Stencil
+    def __init__(self, text):
+      self._text = text
+
+    def __str__(self):
+      return self._text
+
+  ours = core.from_file(soda_path('jacobi2d.soda'), iterate=4)
+  parser = argparse.ArgumentParser()
+  hip.add_arguments(parser)
+  out = str(tmp_path / 'k.hip')
+  hip.print_code(Foreign(str(ours)), parser.parse_args(['--hip-kernel', out]))
+  text = open(out).read()
+  assert 'jacobi2d_march2d_T4' in text and 'extern "C" __global__' in text
+  ref = str(tmp_path / 'r.hip')
+  hip.print_code(ours, parser.parse_args(['--hip-kernel', ref]))
+  assert open(ref).read() == text
