@@ -365,12 +365,21 @@ def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
     return max(1, -(-n // chunks))
   k_min = 4 if warm <= 12 else 2
   simds = NUM_CUS * 4
+  cap = waves_per_simd(vgprs)      # waves per SIMD the registers allow
   best = None
   for chunk in range(min(n, 8), n + 1):
     chunks = -(-n // chunk)
     blocks = others * -(-chunks // along)
     waves = blocks * waves_per_block
-    k = max(k_min, -(-waves // simds))
+    k = -(-waves // simds)
+    if k >= cap and waves > 0.975 * k * simds:
+      # a register-limited grid that fills the last 2-3 % of its wave slots
+      # runs slower than one a chunk-row longer that leaves them free (T=12 on
+      # 8192^2: chunk 97 = 3060 waves on 3072 slots 155-157 us; chunks 98-102 =
+      # 3024-2916 waves 151-152 us; in bench.py steps: neutral on 8192 rows,
+      # 0.555 vs 0.62 ms on the 2248-row slab of a 4-GPU run)
+      k += 1
+    k = max(k_min, k)
     # a lone wave issues at half rate; two waves still leave dependency
     # bubbles (measured ~20 % on the VALU-bound fused kernels)
     cost = k * (2.0 if k == 1 else 1.2 if k == 2 else 1.0) * (chunk + warm)
