@@ -115,12 +115,41 @@ def cpu_baseline(stencil, extent, target_seconds):
   }
 
 
+def launch_ranks(args) -> int:
+  """`bench.py --gpus N` started by hand (no WORLD_SIZE in the environment):
+  this process becomes the launcher.  It touches no GPU (counting devices does
+  not initialise one), starts N fresh rank processes through torchrun on the
+  loopback address and returns their exit status; rank 0 writes the JSON line
+  straight to the stdout the ranks inherit."""
+  import socket
+  import subprocess
+  import torch
+  have = torch.cuda.device_count()
+  if have < args.gpus:
+    sys.stderr.write('bench.py: --gpus %d needs %d GPUs on this node, %d '
+                     'visible; nothing was launched\n' %
+                     (args.gpus, args.gpus, have))
+    return 2
+  sock = socket.socket()
+  sock.bind(('127.0.0.1', 0))
+  port = sock.getsockname()[1]
+  sock.close()
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only (RCCL)
+  return subprocess.run(cmd, env=env).returncode
+
+
 def main():
   args = parse_args()
   # the C-ABI library is a build artefact (git-ignored): make sure it exists;
   # a no-op when it is newer than its sources
   import __graft_entry__ as entry
   entry.build_library()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(launch_ranks(args))
   import torch
   from soda_amd import core, dist as sdist, runtime
   from soda_amd.codegen.hip import lower
@@ -130,9 +159,6 @@ def main():
   emulate = args.emulate_slab if world == 1 else 0
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('--gpus %d needs torchrun --nproc-per-node %d' %
-                       (args.gpus, args.gpus))
     raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
@@ -146,6 +172,9 @@ def main():
       tdist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     else:
       tdist.init_process_group('nccl', device_id=dev)
+    rccl_world = tdist.get_world_size()
+  else:
+    rccl_world = 0      # one rank: no process group, RCCL not involved
 
   stencil = core.from_file(args.soda, iterate=args.iterate)
   extent = list(args.extent)
@@ -162,8 +191,7 @@ def main():
 
   # the depth the lowering really fuses (3-D programs cap it, a program that
   # cannot iterate has none): a dry lowering tells, no GPU needed
-  dry = options(fuses)
-  dry.vec = runtime.pick_vec(stencil, extent)
+  dry = runtime.resolve_options(stencil, options(fuses), extent)
   fuse = lower.lower(stencil, dry).sorted_passes()[0].fused_iters
   geo_world, geo_rank = (emulate, emulate // 2) if emulate > 1 else (world, rank)
   if geo_world == 1:
@@ -213,10 +241,22 @@ def main():
                     lext, iterate=iters, stream=stream, origin=slab.origin,
                     global_extent=slab.extent)
 
+  # A sustained iterated run: the input of a step is the output of the step
+  # before it.  On N > 1 GPUs the ghost rows of that input are stale, so every
+  # step opens with a halo exchange (then one more per K iterations, if K <
+  # iterate); the arrays rotate through the pool and the array that holds the
+  # state is never written while it is read.
+  pool = [a_bufs, b_bufs] + ([c_bufs] if c_bufs else [])
+  state = {'cur': a_bufs, 'first': True}
+
   def one_step():
-    # a step always starts from the same buffers; ghosts of a_bufs are fresh
-    return sdist.run(slab, a_bufs, b_bufs, c_bufs or b_bufs, step_fn,
-                     args.iterate, tdist)
+    cur = state['cur']
+    others = [x for x in pool if x is not cur]
+    res = sdist.run(slab, cur, others[0], others[-1], step_fn, args.iterate,
+                    tdist, ghosts_fresh=state['first'] or world == 1)
+    state['first'] = False
+    state['cur'] = next(x for x in pool if x[0] is res[0])
+    return res
 
   def barrier():
     if tdist is not None:
@@ -320,8 +360,9 @@ def main():
     _orig_step(dst, src, lext, iters)
     launches_per_step += prog.last_launches()[0]
 
-  sdist.run(slab, a_bufs, b_bufs, c_bufs or b_bufs, counting_step,
-            args.iterate, tdist)
+  step_fn_real, step_fn = step_fn, counting_step
+  one_step()
+  step_fn = step_fn_real
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
@@ -364,6 +405,7 @@ def main():
       'metric': 'stencil cells*iters/s, %s %s iterate=%d' %
                 (stencil.app_name, 'x'.join(map(str, extent)), args.iterate),
       'value': value, 'unit': 'cells*iters/s', 'n_gpus': world,
+      'rccl_world': rccl_world,
       **({'emulated_n_gpus': emulate} if emulate > 1 else {}),
       'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
@@ -379,8 +421,15 @@ def main():
           'decomposition': ('slabs along dim %d, %d ghost rows per side, '
                             '%d halo exchange(s) per step' %
                             (stencil.dim - 1, slab.ghost_hi or slab.ghost_lo,
-                             sdist.rounds(args.iterate, ex) - 1))
+                             sdist.rounds(args.iterate, ex)))
                            if world > 1 else 'none',
+          # steps are chained (each starts from the previous step's output),
+          # so on N > 1 GPUs every step opens with a halo exchange
+          'exchanges_per_step': sdist.rounds(args.iterate, ex)
+                                if world > 1 else 0,
+          'ghost_rows_per_side': (slab.ghost_hi or slab.ghost_lo)
+                                 if geo_world > 1 else 0,
+          'ghost_row_fraction': (slab.rows - slab.own_rows) / float(slab.rows),
           'launches_per_step': launches_per_step,
           'passes': [p.fused_iters for p in prog.module.sorted_passes()],
       },

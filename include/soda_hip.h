@@ -49,14 +49,14 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 3
+#define SODA_HIP_ABI_VERSION 4
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
 #define SODA_HIP_MAX_KERNELS 32
 #define SODA_HIP_MAX_PASSES 8
 #define SODA_HIP_MAX_PASS_KERNELS 16
 #define SODA_HIP_MAX_PARAMS 8
-#define SODA_HIP_NAME_LEN 64
+#define SODA_HIP_NAME_LEN 96
 
 enum soda_hip_status {
   SODA_HIP_OK = 0,
@@ -203,6 +203,13 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           const soda_hip_host_tensor_t* outputs,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi);
+
+/* Diagnostics: kernels generated with time stamps (sodac --hip-stamps) write
+ * four 64-bit words per wavefront -- s_memtime at entry and exit, HW_ID,
+ * XCC_ID -- to this device buffer (slot SODA_HIP_MAX_TENSORS - 1 of the kernel
+ * arguments; at least 32 bytes x wavefronts of the largest launch).  NULL
+ * (the default) for kernels without stamps. */
+int soda_hip_program_set_debug_buffer(soda_hip_program_t* program, void* buf);
 
 /* Number of kernel launches the last run_device/run_host call issued and how
  * many of them used the pass with the largest fused_iters. */

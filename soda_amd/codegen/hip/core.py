@@ -94,9 +94,8 @@ def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
     # re-read it
     stencil = core.from_text(str(stencil))
   if args.hip_kernel is not None:
-    opts = options_from_args(args)
-    if opts.vec is None:
-      opts.vec = lower.default_vec(stencil)
+    from soda_amd import runtime
+    opts = runtime.resolve_options(stencil, options_from_args(args), None)
     with tempfile.TemporaryFile(mode='w+') as tmp:
       tmp.write(lower.lower(stencil, opts).source)
       tmp.seek(0)

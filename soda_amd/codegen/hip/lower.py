@@ -34,6 +34,7 @@ text), march.py (`march2d` / `march3d`), direct.py, lds2d.py (the classic LDS
 halo tile, kept as the measured alternative); this file holds the options and
 `lower()`, which picks the shape.
 """
+import os
 from typing import Optional, Sequence
 
 from soda_amd import core, util
@@ -53,6 +54,9 @@ from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_FUSE_PRESERVE,  # noqa:
 # whole module
 # ---------------------------------------------------------------------------
 
+DEFAULT_COUNTED_WAITS = False
+
+
 class LowerOptions:
   """Knobs of the HIP backend (command-line spelling: --hip-*).  `None` means
   "the measured default for this program's dimensionality" (profiles/
@@ -71,7 +75,22 @@ class LowerOptions:
                lane_shift: str = 'dpp', min_waves: int = 0,
                occupancy: int = 0, buffer_ops: bool = True,
                pipe: Optional[int] = None, pipe_rows: int = 2,
-               reg_budget: Optional[int] = None):
+               reg_budget: Optional[int] = None,
+               counted_waits: Optional[bool] = None, stamps: bool = False,
+               peel=None):
+    self.stamps = stamps
+    # trips of the unrolled loop whose warm-up is peeled into straight-line
+    # code without the stages that do not matter yet: an int for every fusion
+    # depth, a dict {depth: trips}, -1 = all of the warm-up, None = let
+    # runtime.select_peel choose per kernel from the compiled register counts
+    # (lower() itself treats None as -1)
+    self.peel = peel
+    # None: the default (DEFAULT_COUNTED_WAITS; SODA_HIP_COUNTED_WAITS=0/1
+    # overrides it for A/B runs of the whole test suite)
+    if counted_waits is None:
+      env = os.environ.get('SODA_HIP_COUNTED_WAITS')
+      counted_waits = DEFAULT_COUNTED_WAITS if env is None else env == '1'
+    self.counted_waits = counted_waits
     # estimated VGPRs a marching shape may need before the ladder in lower()
     # moves on to a leaner one (None: REG_BUDGET)
     self.reg_budget = reg_budget
@@ -109,7 +128,8 @@ class LowerOptions:
                        self.edge_loads, self.tile_rows, self.warm_guards,
                        self.interleave, self.lane_shift, self.min_waves,
                        self.occupancy, self.buffer_ops, self.pipe,
-                       self.pipe_rows, self.reg_budget)
+                       self.pipe_rows, self.reg_budget, self.counted_waits,
+                       self.stamps, self.peel)
     if out.prefetch is None and dim == 3:
       out.prefetch = 1
     # 2-D: resolved per fusion depth in lower() (default_prefetch)
@@ -196,6 +216,13 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     depths = sorted({min(t, cap) for t in opts.fuse if iterable} - {0, 1},
                     reverse=True)
 
+    def peel_for(t: int) -> int:
+      if opts.peel is None:
+        return -1
+      if isinstance(opts.peel, dict):
+        return int(opts.peel.get(t, -1))
+      return int(opts.peel)
+
     def pipe_for(t: int) -> int:
       want = default_pipe(t) if opts.pipe is None else opts.pipe
       ok = (want > 1 and t > 1 and t % want == 0 and opts.buffer_ops and
@@ -211,7 +238,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
                         opts.interleave,
                         opts.lane_shift, opts.min_waves, opts.occupancy,
                         opts.buffer_ops,
-                        pipe_for(t), opts.pipe_rows)
+                        pipe_for(t), opts.pipe_rows, opts.counted_waits,
+                        opts.stamps, peel_for(t))
       cfg.chunk_fixed = opts.chunk_rows is not None
       return cfg
 

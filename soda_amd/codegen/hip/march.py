@@ -90,7 +90,25 @@ class MarchConfig:
                tile_rows: int = 6, warm_guards: bool = False,
                interleave: bool = False, lane_shift: str = 'dpp',
                min_waves: int = 0, occupancy: int = 0,
-               buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4):
+               buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4,
+               counted_waits: bool = False, stamps: bool = False,
+               peel: int = -1):
+    # the pipeline warm-up of a chunk as straight-line code in front of the
+    # loop, WITHOUT the stages whose rows cannot reach an output row of the
+    # chunk yet (fused iteration l first matters 2l row steps into the chunk:
+    # T = 12 computes 156 of its first 288 stage-rows for nothing otherwise)
+    # (in whole trips of the unrolled loop; -1: all the warm-up, 0: none.  The
+    # last trips are nearly full row steps, save little and can cost registers
+    # -- T = 12: 159 VGPRs with 2 of its 4 trips peeled, 231 with all four --
+    # so runtime.select_peel picks the count per kernel from compiled code)
+    self.peel = int(peel)
+    # diagnostics: every wave records s_memtime at entry and exit and where it
+    # ran (tools/timeline.py)
+    self.stamps = stamps
+    # input rows loaded by inline-asm loads the compiler does not count, with
+    # one hand-counted `s_waitcnt vmcnt(N)` per row step (soda_rt.h): hipcc's
+    # own waits drain the whole prefetch queue once per trip of the loop
+    self.counted_waits = counted_waits and buffer_ops
     # row steps per barrier of a stage-pipelined block (power of two): the
     # waves synchronise once per `pipe_rows` rows through a ring of twice
     # that many slots
@@ -114,7 +132,10 @@ class MarchConfig:
     # (amdgpu_waves_per_eu); 0 = let it use what it wants
     self.min_waves = min_waves
     # how a row is shifted by one lane: 'dpp' (wave_shr/shl fused into the
-    # consuming add) or 'bperm' (ds_bpermute_b32, issued one stage early)
+    # consuming add), 'bperm' (ds_bpermute_b32, issued one stage early), 'swz'
+    # (ds_swizzle rotate + a readlane/writelane patch for the lane that crosses
+    # the 32-lane halves) or 'swzh' (ds_swizzle rotate alone: the wave holds
+    # two independent 32-lane half strips, each with its own halo lanes)
     self.lane_shift = lane_shift
     # emit a stage's cells operation-major (independent statements back to
     # back).  Measured SLOWER on gfx950 (T=12: 186 vs 151 us): a wave64 VALU op
@@ -148,12 +169,18 @@ class MarchConfig:
             '_wg' if self.warm_guards else '') + (
                 '_il' if self.interleave else '') + (
                     '_bp' if self.lane_shift == 'bperm' else
+                    '_swz' if self.lane_shift == 'swz' else
+                    '_swzh' if self.lane_shift == 'swzh' else
                     '_noshift' if self.lane_shift == 'none' else '') + (
                         '_mw%d' % self.min_waves if self.min_waves else '') + (
                             '_occ%d' % self.occupancy if self.occupancy else '') + (
+                                '_cw' if self.counted_waits else
                                 '_buf' if self.buffer_ops else '') + (
                                     '_pipe%dx%d' % (self.pipe, self.pipe_rows)
-                                    if self.pipe > 1 else '')
+                                    if self.pipe > 1 else '') + (
+                                        '_st' if self.stamps else '') + (
+                                            '' if self.peel < 0 else
+                                            '_k%d' % self.peel)
 
 
 March2DConfig = MarchConfig   # older name
@@ -296,7 +323,10 @@ class _MarchKernel:
     # separate narrow loads (so a 1-iteration strip keeps all 64 lanes valid and
     # its rows start on a 64*V-cell boundary)
     self.edge = (0, 0)
-    if self.cfg.edge_loads:
+    # lanes that form one strip: the whole wave, or each 32-lane half
+    self.group = 32 if self.cfg.lane_shift == 'swzh' else 64
+    if self.cfg.edge_loads and self.cfg.lane_shift in ('dpp', 'none'):
+      # (the edge cells enter through DPP's `old` operand)
       lo = hi = 0
       for stage in self.st.ordered_stages:
         for pname in stage.taps:
@@ -333,10 +363,11 @@ class _MarchKernel:
         self.nodes, self.inputs, self.outputs = _build_chain(
             self.st, self.T, self.PF, self.edge, self.W, self.R)
         self.out_nodes = list(self.outputs.values())
-    if self.lanes_lo + self.lanes_hi >= 32:
+    if self.lanes_lo + self.lanes_hi >= self.group // 2:
       raise util.SemanticError('march: halo of %d+%d cells is too wide for a '
-                               '64-lane strip at %d cells per lane' %
-                               (self.margin_lo, self.margin_hi, self.V))
+                               '%d-lane strip at %d cells per lane' %
+                               (self.margin_lo, self.margin_hi, self.group,
+                                self.V))
     # 3-D: rows (dim 1) of a tile held in registers
     if self.dim == 3:
       self.rhalo_lo = max(n.rmargin[0] for n in self.out_nodes)
@@ -401,7 +432,15 @@ class _MarchKernel:
     for n in self.out_nodes:
       self.back_lo[id(n)] = 0
     for n in reversed(self.nodes):
-      if n.stage is None or self.back_lo[id(n)] is None:
+      if self.back_lo[id(n)] is None:
+        continue
+      if n.mirror_of is not None:      # the same planes, held by another wave
+        src = n.mirror_of
+        if self.back_lo[id(src)] is None or \
+            self.back_lo[id(n)] < self.back_lo[id(src)]:
+          self.back_lo[id(src)] = self.back_lo[id(n)]
+        continue
+      if n.stage is None:
         continue
       for pname, pnode in n.parents.items():
         tlo, _ = n.tap_bounds(pname)
@@ -409,7 +448,8 @@ class _MarchKernel:
         if self.back_lo[id(pnode)] is None or cand < self.back_lo[id(pnode)]:
           self.back_lo[id(pnode)] = cand
 
-    self.strip_lanes = 64 - self.lanes_lo - self.lanes_hi
+    self.group_lanes = self.group - self.lanes_lo - self.lanes_hi
+    self.strip_lanes = self.group_lanes * (64 // self.group)
     self.strip_cells = self.strip_lanes * self.V
     self.max_delay = max(n.delay for n in self.out_nodes)
     bounds = self.st.window_bounds(self.T)
@@ -426,6 +466,22 @@ class _MarchKernel:
     # compute ticks before a chunk's first output
     self.warm = self.max_delay - self.m_lo - self.lead
 
+    # peeled warm-up: row steps in front of the loop (a whole number of loop
+    # trips, so the register slots line up) in which a stage is emitted only
+    # from the step on at which its rows start to matter
+    self.peeled = 0
+    self.peel_trips_max = 0
+    if self.W == 1:
+      steps = -(-self.warm // self.U) * self.U
+      stages = [n for n in self.nodes if n.stage is not None]
+      skipped = sum(1 for i in range(steps) for n in stages
+                    if not self.stage_needed(n, i))
+      if skipped * 4 >= steps * len(stages):
+        self.peel_trips_max = steps // self.U
+        trips = self.peel_trips_max if self.cfg.peel < 0 else min(
+            self.cfg.peel, self.peel_trips_max)
+        self.peeled = trips * self.U
+
     self.kind = 'march%dd' % self.dim
     self.name = '%s_%s_%s' % (self.st.app_name, self.kind, self.cfg.key())
     self.waves = self.cfg.waves_x * self.cfg.waves_y if self.dim == 2 else 1
@@ -440,6 +496,49 @@ class _MarchKernel:
   def rows_of(self, n: _Node):
     return range(n.rmargin[0], self.rows_in - n.rmargin[1])
 
+  def stage_needed(self, n: _Node, step: int) -> bool:
+    """Does the plane `n` computes `step` row steps into a chunk (counted from
+    the first step of the loop) reach any output plane of the chunk?"""
+    lo = self.back_lo[id(n)]
+    if lo is None:
+      return False
+    return self.m_lo + self.lead + step >= lo + n.delay
+
+  # -- counted waits: raw register groups of the asm loads ---------------------
+  @staticmethod
+  def _groups(nbytes: int) -> List[int]:
+    """Bytes of each load instruction that fetches a `nbytes` fragment."""
+    return [16] * (nbytes // 16) if nbytes % 16 == 0 else [nbytes]
+
+  _RAW_TYPE = {16: 'soda_u32x4', 8: 'soda_u32x2', 4: 'unsigned', 2: 'unsigned',
+               1: 'unsigned'}
+
+  def raw_groups(self, n: _Node, slot: int, j: int):
+    """(variable, bytes, byte offset in the fragment, edge index or None) of
+    every load instruction that fills row j of `slot` of input `n`."""
+    es = self.esz[n.key[1]]
+    out = []
+    for g, nb in enumerate(self._groups(self.V * es)):
+      out.append(('%s_s%d_r%d_q%d' % (n.var, slot, j, g), nb, 16 * g, None))
+    for i in range(self.n_edge):
+      out.append(('%s_s%d_r%d_qe%d' % (n.var, slot, j, i), es, 0, i))
+    return out
+
+  def vmem_per_tick(self, wv: int):
+    """(load, store) instructions wave `wv` issues per row step."""
+    nl = ns = 0
+    if wv == 0:
+      for n in self.inputs.values():
+        nl += len(self.rows_of(n)) * len(self.raw_groups(n, 0, 0))
+    for o, n in self.outputs.items():
+      if n.owner == wv:
+        ns += len(self.store_rows(n)) * len(self._groups(self.V * self.esz[o]))
+    return nl, ns
+
+  def store_rows(self, n: _Node):
+    return range(max(n.rmargin[0], self.rhalo_lo),
+                 self.rows_in - max(n.rmargin[1], self.rhalo_hi))
+
   @staticmethod
   def slot_of(n: _Node, k: int, age: int) -> int:
     return (k - age) % n.slots
@@ -450,6 +549,15 @@ class _MarchKernel:
     self._emit_addressing()
     for wv in range(self.W):
       self._emit_wave(wv)
+    if self.cfg.stamps:
+      self.w('  if (lane == 0) {')
+      self.w('    unsigned long long* d = (unsigned long long*)a.buf[15] + '
+             '4ull * ((unsigned long long)blockIdx.x * %d + wave);' % self.waves)
+      self.w('    d[0] = soda_t0;')
+      self.w('    d[1] = __builtin_amdgcn_s_memtime();')
+      self.w('    d[2] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID')
+      self.w('    d[3] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID')
+      self.w('  }')
     self.w('}')
     return self._finish()
 
@@ -473,6 +581,8 @@ class _MarchKernel:
       % (self.block, '__attribute__((amdgpu_waves_per_eu(%d, %d))) ' %
          (self.cfg.min_waves, max(self.cfg.min_waves, 8))
          if self.cfg.min_waves else '', self.name))
+    if self.cfg.stamps:
+      self.w('  const unsigned long long soda_t0 = __builtin_amdgcn_s_memtime();')
     self.w('  const int lane = (int)(threadIdx.x & 63u);')
     self.w('  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));')
     if self.cfg.xcd_swizzle:
@@ -504,8 +614,14 @@ class _MarchKernel:
       self.w('  const int y0 = tile_y * %d - %d;  // first row held' %
         (self.tile_rows, self.rhalo_lo))
       self.w('  const int64_t pitch_y = a.stride[1];')
-    self.w('  const int x0 = strip * %d + (lane - %d) * %d;' %
-      (self.strip_cells, self.lanes_lo, self.V))
+    if self.group == 64:
+      self.w('  const int sub = lane;')
+      self.w('  const int x0 = strip * %d + (lane - %d) * %d;' %
+        (self.strip_cells, self.lanes_lo, self.V))
+    else:     # two half strips side by side, each with its own halo lanes
+      self.w('  const int sub = lane & %d;' % (self.group - 1))
+      self.w('  const int x0 = strip * %d + (lane >> 5) * %d + (sub - %d) * %d;'
+        % (self.strip_cells, self.group_lanes * self.V, self.lanes_lo, self.V))
     # chunk length is a launch-time value (kernel descriptor tile / waves): the
     # host sizes it so the grid fills the GPU in whole rounds of waves
     self.w('  const int chunk_len = a.tile[%d] / %d;' %
@@ -515,13 +631,14 @@ class _MarchKernel:
     self.w('  if (m_begin >= nm || strip * %d >= n0) return;  // wave-uniform' %
       self.strip_cells)
     self.w('  const bool lane_ok = x0 >= 0 && x0 + %d <= n0;' % self.V)
-    self.w('  const bool store_ok = lane_ok && lane >= %d && lane < %d;' %
-      (self.lanes_lo, 64 - self.lanes_hi))
+    self.w('  const bool store_ok = lane_ok && sub >= %d && sub < %d;' %
+      (self.lanes_lo, self.group - self.lanes_hi))
     self.w('  const int64_t pitch = a.stride[%d];' % self.ax)
     self.w('  const int64_t x0c = lane_ok ? (int64_t)x0 : 0;')
 
   def _emit_addressing(self) -> None:
     self.buf = self.cfg.buffer_ops
+    self.cw = self.cfg.counted_waits and self.buf
     table0 = self.st.symbol_table
     self.esz = {nme: table0[nme].size_in_bytes for nme in list(self.inputs) + list(self.outputs)}
     self.n_edge = max(self.edge)
@@ -581,6 +698,7 @@ class _MarchKernel:
                  'a.origin[0] + x0 + %d < a.gextent[0] - %d);'
                  % (o, e, e, max(0, -wlo[0]), e, max(0, whi[0])))
     self.use_bperm = self.cfg.lane_shift == 'bperm'
+    self.use_swz = self.cfg.lane_shift in ('swz', 'swzh')
     if self.use_bperm:
       self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
       self.w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
@@ -612,11 +730,23 @@ class _MarchKernel:
               self.w('  %s %s_s%d_r%d_e[%d];' % (n.ctype, n.var, s, j, self.n_edge))
               self.w('  soda_zero_frag<%s, %d>(%s_s%d_r%d_e);' %
                 (n.ctype, self.n_edge, n.var, s, j))
+            if n.is_input and self.cw:
+              for var, nb, _, _ in self.raw_groups(n, s, j):
+                self.w('  %s %s = {};' % (self._RAW_TYPE[nb], var))
 
-  def emit_loads(self, k: int, t_expr: str) -> None:
-      """Issues the loads of input plane t (tick phase k)."""
+  def emit_loads(self, k: int, t_expr: str, pin: bool = False) -> None:
+      """Issues the loads of input plane t (tick phase k).  `pin`: the step is
+      straight-line code (peeled warm-up); its loads take their lane offset
+      from an opaque copy made here, or the compiler hoists the loads of ALL
+      peeled steps to the top of the kernel (T = 12: 229 instead of 159
+      VGPRs)."""
       self.w('      const int t = %s;' % t_expr)
       self.w('      const bool plane_ok = t >= 0 && t < in_end;')
+      if pin and self.buf and not self.cw:
+        for es in sorted({self.esz[nme] for nme in self.inputs}):
+          self.w('      unsigned xb%dp = xb%d; asm volatile("" : "+v"(xb%dp));'
+                 % (es, es, es))
+      pinned = 'p' if pin and self.buf and not self.cw else ''
       if self.buf:
         in_es = sorted({self.esz[nme] for nme in self.inputs})
         for es in in_es:
@@ -631,12 +761,22 @@ class _MarchKernel:
                 (es, j, j, j, es, j, es))
       for nme, n in self.inputs.items():
         s = self.slot_of(n, k, 0)
-        for j in (self.rows_of(n) if self.buf else []):
+        for j in (self.rows_of(n) if self.cw else []):
+          es = self.esz[nme]
+          ro = 'ro%d' % es if self.dim == 2 else 'ro%d_%d' % (es, j)
+          for var, nb, boff, ei in self.raw_groups(n, s, j):
+            if ei is None:
+              self.w('      soda_asm_buf_load<%d, %s>(%s, r_%s, %s + xb%d + %du);'
+                     % (nb, self.nt_l, var, nme, ro, es, boff))
+            else:
+              self.w('      soda_asm_buf_load<%d, false>(%s, r_%s, %s + exb%d_%d);'
+                     % (nb, var, nme, ro, ei, es))
+        for j in (self.rows_of(n) if self.buf and not self.cw else []):
           es = self.esz[nme]
           ro = 'ro%d' % es if self.dim == 2 else 'ro%d_%d' % (es, j)
           reg = '%s_s%d_r%d' % (n.var, s, j)
-          self.w('      soda_buf_load_frag<%s, %d, %s>(%s, r_%s, %s + xb%d);' %
-            (n.ctype, self.V, self.nt_l, reg, nme, ro, es))
+          self.w('      soda_buf_load_frag<%s, %d, %s>(%s, r_%s, %s + xb%d%s);' %
+            (n.ctype, self.V, self.nt_l, reg, nme, ro, es, pinned))
           for i in range(self.n_edge):
             self.w('      { %s e1[1]; soda_buf_load_frag<%s, 1, false>(e1, r_%s, %s + '
               'exb%d_%d); %s_e[%d] = e1[0]; }' %
@@ -670,26 +810,103 @@ class _MarchKernel:
     # load-only prologue whose slot phases continue into tick 0 of the loop.
     self.w('  int tau = m_begin + (%d);' % (self.m_lo + self.lead))
     if wv == 0:
+      if self.cw:
+        # the descriptors come out of scalar/readfirstlane arithmetic; asm loads
+        # get no hazard padding from the compiler (cdna_hip_programming.md 5.7)
+        self.w('  asm volatile("s_nop 4");')
       for i in range(self.lead):
         self.w('    {  // prologue: loads of plane tau - %d' % (self.lead - i))
         self.emit_loads((i - self.lead) % self.U, 'tau - %d' % (self.lead - i))
+        if self.cw:
+          self._emit_dummy_stores(wv)
         self.w('    }')
     self.w('  const int tau_end = m_end + %d;' % self.max_delay)
+    if self.peeled:
+      self.w('  {  // warm-up: %d row steps, stages enter as their rows start '
+             'to matter' % self.peeled)
+      for i in range(self.peeled):
+        self._emit_tick(wv, i % self.U, step=i)
+      self.w('  }')
+      self.w('  tau += %d;' % self.peeled)
     self.w('  for (; tau < tau_end; tau += %d) {' % self.U)
     for k in range(self.U):
       self._emit_tick(wv, k)
     self.w('  }')
     if self.W > 1:
+      if self.cw and wv == 0:
+        # the rows prefetched past the chunk (out of range: dropped by the
+        # memory pipeline) must have retired before the registers are reused
+        # by code the compiler places behind this branch
+        self.w('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
       self.w('  }')
 
-  def _emit_tick(self, wv: int, k: int) -> None:
+  def _emit_dummy_stores(self, wv: int, only: Optional[_Node] = None,
+                         salt: int = 0) -> None:
+    """Counted waits: a load-only prologue step still issues the stores of a
+    row step, out of range (the memory pipeline drops them), so that every step
+    of the wave is the same sequence of vector-memory instructions and ONE
+    constant serves every wait."""
+    # every dummy store gets an out-of-range offset of its own: identical
+    # stores would be merged by the compiler's dead-store elimination and the
+    # hand count would be off (found by tools/waitcheck.py on heat3d)
+    i = 64 * salt
+    for o, n in self.outputs.items():
+      if n.owner != wv or (only is not None and n is not only):
+        continue
+      es = self.esz[o]
+      for j in self.store_rows(n):
+        self.w('      soda_buf_store_frag<%s, %d, %s>(w_%s, SODA_OOB_ROW + sxb%d + '
+               '%du, %s_s0_r%d);' % (n.ctype, self.V, self.nt_s, o, es,
+                                     4096 * i, n.var, j))
+        i += 1
+
+  def _emit_wait(self, wv: int, k: int) -> None:
+    """Counted waits: the input rows loaded PF steps ago are the youngest any
+    stage reads in this step.  Loads and stores retire in issue order, and every
+    step issues `nl` loads then `ns` stores, so all but the PF * (nl + ns)
+    youngest instructions must have completed."""
+    nl, ns = self.vmem_per_tick(wv)
+    count = min(63, self.PF * (nl + ns))      # vmcnt is a 6-bit counter
+    groups = []
+    unpack = []
+    for nme, n in self.inputs.items():
+      slot = self.slot_of(n, k, self.PF)
+      for j in self.rows_of(n):
+        typed = '%s_s%d_r%d' % (n.var, slot, j)
+        for g, (var, nb, boff, ei) in enumerate(self.raw_groups(n, slot, j)):
+          groups.append(var)
+          if ei is None:
+            unpack.append('      soda_unpack_frag<%s, %d>(%s, %s, %d);' %
+                          (n.ctype, self.V, typed, var, g))
+          else:
+            unpack.append('      { %s e1[1]; soda_unpack_frag<%s, 1>(e1, %s); '
+                          '%s_e[%d] = e1[0]; }' % (n.ctype, n.ctype, var, typed,
+                                                   ei))
+    first = True
+    while groups:
+      part, groups = groups[:4], groups[4:]
+      if first:
+        self.w('      SODA_WAIT_%d(%d, %s);' % (len(part), count,
+                                                ', '.join(part)))
+        first = False
+      else:
+        self.w('      SODA_TIE_%d(%s);' % (len(part), ', '.join(part)))
+    self.L.extend(unpack)
+
+  def _emit_tick(self, wv: int, k: int, step: Optional[int] = None) -> None:
+    """One row step at slot phase k; `step` = its number within the peeled
+    warm-up (None: a step of the loop)."""
+    at = k if step is None else step
     self.w('    {  // tick %d of %d' % (k, self.U))
+
     if self.W > 1 and k % self.R == 0:
       self.w('      soda_pipe_barrier();')
     if wv == 0:
-      self.emit_loads(k, 'tau + %d' % k)
+      self.emit_loads(k, 'tau + %d' % at, pin=step is not None)
+      if self.cw:
+        self._emit_wait(wv, k)
     else:
-      self.w('      const int t = tau + %d;' % k)
+      self.w('      const int t = tau + %d;' % at)
     for n in self.nodes:
       if n.mirror_of is not None and n.owner == wv:
         # the plane the previous wave wrote R ticks (one barrier) ago
@@ -703,6 +920,10 @@ class _MarchKernel:
     self._stage_mark = len(self.L)
     for n in self.nodes:
       if n.stage is not None and n.owner == wv:
+        if step is not None and not self.stage_needed(n, step):
+          if self.cw and n.store_slot is not None:
+            self._emit_dummy_stores(wv, only=n, salt=step + 1)
+          continue
         self._emit_stage(n, k)
     self.shift_temps = max(self.shift_temps, len(self._shifted))
     self.w('    }')
@@ -755,6 +976,11 @@ class _MarchKernel:
           for _ in range(abs(lane_off)):
             expr = 'soda_lane_from(%s, %s)' % (
                 'lane_dn_addr' if lane_off < 0 else 'lane_up_addr', expr)
+        elif self.use_swz:
+          expr = src
+          for _ in range(abs(lane_off)):
+            expr = 'soda_lane_%s%d(%s)' % ('dn' if lane_off < 0 else 'up',
+                                           self.group, expr)
         else:
           expr = src
           for _ in range(abs(lane_off)):
@@ -763,8 +989,8 @@ class _MarchKernel:
         line = '      const %s %s = %s;' % (p.ctype, tmp, expr)
         # a shift of a row produced in an EARLIER tick can be issued ahead
         # of the previous stage's arithmetic (latency hidden behind it)
-        early = self.use_bperm and (p.is_input or age > 0) and not (
-            p.is_input and self.n_edge)
+        early = (self.use_bperm or self.use_swz) and (
+            p.is_input or age > 0) and not (p.is_input and self.n_edge)
         (_early if early else _pre).append(line)
         self._shifted[key] = tmp
       return self._shifted[key]
@@ -875,8 +1101,7 @@ class _MarchKernel:
       self.w('      {')
       self.w('        const int m = t - %d;' % n.delay)
       self.w('        const bool m_ok = m >= m_begin && m < m_end;')
-      for j in range(max(n.rmargin[0], self.rhalo_lo),
-                     self.rows_in - max(n.rmargin[1], self.rhalo_hi)):
+      for j in self.store_rows(n):
         reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
         if self.dim == 3:
           self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
@@ -928,7 +1153,9 @@ class _MarchKernel:
                    tune=dict(axis=self.ax, waves_along=self.cfg.waves_y if self.dim == 2 else 1,
                              waves_per_block=self.waves, warm=self.warm,
                              fixed=self.cfg.chunk_fixed, occupancy=self.cfg.occupancy,
-                             pipe=self.W,
+                             pipe=self.W, peel_trips=self.peeled // self.U,
+                             peel_trips_max=self.peel_trips_max,
+                             fused=self.T,
                              window_extra=(self.m_hi - self.m_lo) if self.buf else None,
                              max_elem=max(self.esz.values()))),
         '\n'.join(self.L) + '\n')

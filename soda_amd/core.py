@@ -149,6 +149,12 @@ class Stencil:
                 (stmt.name, var.name))
         if isinstance(node, ir.Let):
           lets.add(node.name)
+    # the one optimisation pass the reference always runs, at this very point
+    # (ref core.py:134-138: after simplify, before type propagation)
+    self._cr_counter = 0
+    from soda_amd.optimization import inline
+    inline.rebalance(self)
+    table = self.symbol_table
     typed = dict(table)
     typed.update((p.name, p.haoda_type) for p in self.param_stmts)
     for stmt in self.local_stmts + self.output_stmts:
@@ -158,6 +164,15 @@ class Stencil:
         [Stage(s, False, self.param_names) for s in self.local_stmts] +
         [Stage(s, True, self.param_names) for s in self.output_stmts])
     self._check_dag()
+
+  def new_cr_var(self) -> str:
+    """A fresh statement name `cr_var_<n>` (ref core.py:183-191)."""
+    while True:
+      var = 'cr_var_%d' % self._cr_counter
+      self._cr_counter += 1
+      if var not in {s.name for s in
+                     self.input_stmts + self.local_stmts + self.output_stmts}:
+        return var
 
   # -- names and types -----------------------------------------------------
   @property

@@ -78,6 +78,7 @@ struct soda_hip_program {
   std::vector<DeviceBuffer> host_out;
   int32_t last_launches = 0;
   int32_t last_fused = 0;
+  void* debug = nullptr;              // time-stamp buffer of diagnostic builds
 };
 
 struct soda_hip_event {
@@ -411,6 +412,7 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
   int32_t total = 0;
   if (int rc = schedule(plan, iterate, count, &total)) return rc;
 
+  if (p->debug) base.buf[SODA_HIP_MAX_TENSORS - 1] = p->debug;
   const int in0 = 0, out0 = plan.num_inputs, loc0 = out0 + plan.num_outputs;
   const int prm0 = loc0 + plan.num_locals;
   for (int k = 0; k < plan.num_params; ++k)   // the same in every iteration
@@ -449,6 +451,12 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
         for (int j = 0; j < plan.num_inputs; ++j) src[j] = base.buf[out0 + j];
     }
   }
+  return SODA_HIP_OK;
+}
+
+int soda_hip_program_set_debug_buffer(soda_hip_program_t* p, void* buf) {
+  if (!p) return fail(SODA_HIP_ERR_INVALID, "NULL program");
+  p->debug = buf;
   return SODA_HIP_OK;
 }
 

@@ -249,6 +249,80 @@ template <class T> SODA_DEV T soda_lane_from(int byte_addr, T v) {
   return soda_bperm<T>::get(byte_addr, v);
 }
 
+// ---- lane shifts through ds_swizzle (LDS crossbar, no LDS memory) -----------
+// A DPP-carrying VALU op stalls the vector issue of gfx950 far beyond its own
+// slot (tools/dppbench.py, tools/tickbench.py: the row step of the fused
+// jacobi kernel sustains 3.7-4.0 cycles per instruction with its 6 DPP
+// modifiers, 2.1-2.8 without).  ds_swizzle_b32 in rotate mode moves a register
+// by one lane through the LDS crossbar instead: it issues in the LDS pipe beside
+// the VALU (one issue slot, result after ~50 cycles, counted by lgkmcnt) and,
+// unlike ds_bpermute, needs no address register and a quarter of the LDS time.
+// The rotation is WITHIN each 32-lane half of the wave:
+//   *32 forms: lanes 0/32 (dn) resp. 31/63 (up) receive the value that wrapped
+//              around their half -- for strips laid out as two independent
+//              32-lane halves, whose end lanes are halo lanes anyway;
+//   *64 forms: the one lane that must cross the halves is patched with
+//              v_readlane / v_writelane (two plain VALU ops); lanes 0 (dn) and
+//              63 (up) receive a wrapped value instead of 0: they are halo
+//              lanes of a 64-lane strip.
+// offset = 0xC000 | direction << 10 | amount << 5 (GFX9 rotate mode)
+#define SODA_SWZ_ROT_UP 0xC020   /* lane i <- lane (i + 1) % 32 of its half */
+#define SODA_SWZ_ROT_DN 0xC420   /* lane i <- lane (i - 1) % 32 of its half */
+SODA_DEV int soda_swz_dn32(int v) {
+  return __builtin_amdgcn_ds_swizzle(v, SODA_SWZ_ROT_DN);
+}
+SODA_DEV int soda_swz_up32(int v) {
+  return __builtin_amdgcn_ds_swizzle(v, SODA_SWZ_ROT_UP);
+}
+SODA_DEV int soda_swz_dn64(int v) {
+  int r = __builtin_amdgcn_ds_swizzle(v, SODA_SWZ_ROT_DN);
+  const int s = __builtin_amdgcn_readlane(v, 31);
+  asm("v_writelane_b32 %0, %1, 32" : "+v"(r) : "s"(s));   // no builtin in ROCm 7.2
+  return r;
+}
+SODA_DEV int soda_swz_up64(int v) {
+  int r = __builtin_amdgcn_ds_swizzle(v, SODA_SWZ_ROT_UP);
+  const int s = __builtin_amdgcn_readlane(v, 32);
+  asm("v_writelane_b32 %0, %1, 31" : "+v"(r) : "s"(s));
+  return r;
+}
+
+template <class T, int kSize = sizeof(T)>
+struct soda_swz;
+template <class T>
+struct soda_swz<T, 4> {
+  SODA_DEV T dn32(T v) { return __builtin_bit_cast(T, soda_swz_dn32(__builtin_bit_cast(int, v))); }
+  SODA_DEV T up32(T v) { return __builtin_bit_cast(T, soda_swz_up32(__builtin_bit_cast(int, v))); }
+  SODA_DEV T dn64(T v) { return __builtin_bit_cast(T, soda_swz_dn64(__builtin_bit_cast(int, v))); }
+  SODA_DEV T up64(T v) { return __builtin_bit_cast(T, soda_swz_up64(__builtin_bit_cast(int, v))); }
+};
+template <class T>
+struct soda_swz<T, 8> {
+  struct pair { int lo, hi; };
+#define SODA_SWZ_PAIR(fn)                          \
+  SODA_DEV T fn(T v) {                             \
+    pair p = __builtin_bit_cast(pair, v);          \
+    p.lo = soda_swz_##fn(p.lo);                    \
+    p.hi = soda_swz_##fn(p.hi);                    \
+    return __builtin_bit_cast(T, p);               \
+  }
+  SODA_SWZ_PAIR(dn32) SODA_SWZ_PAIR(up32) SODA_SWZ_PAIR(dn64) SODA_SWZ_PAIR(up64)
+#undef SODA_SWZ_PAIR
+};
+template <class T>
+struct soda_swz<T, 2> {   // widened: one VGPR per element
+  SODA_DEV T dn32(T v) { return (T)soda_swz_dn32((int)v); }
+  SODA_DEV T up32(T v) { return (T)soda_swz_up32((int)v); }
+  SODA_DEV T dn64(T v) { return (T)soda_swz_dn64((int)v); }
+  SODA_DEV T up64(T v) { return (T)soda_swz_up64((int)v); }
+};
+template <class T>
+struct soda_swz<T, 1> : soda_swz<T, 2> {};
+template <class T> SODA_DEV T soda_lane_dn32(T v) { return soda_swz<T>::dn32(v); }
+template <class T> SODA_DEV T soda_lane_up32(T v) { return soda_swz<T>::up32(v); }
+template <class T> SODA_DEV T soda_lane_dn64(T v) { return soda_swz<T>::dn64(v); }
+template <class T> SODA_DEV T soda_lane_up64(T v) { return soda_swz<T>::up64(v); }
+
 // ---- row fragments: V consecutive cells of one row per lane ----------------
 template <class T, int V>
 struct soda_vec {
@@ -379,6 +453,94 @@ SODA_DEV void soda_buf_store_frag(soda_rsrc_t r, unsigned off,
     __builtin_amdgcn_raw_buffer_store_b8(t, r, off, 0, kAux);
   }
 }
+
+// ---- loads the compiler does not count (exact, hand-counted waits) ----------
+// hipcc's s_waitcnt insertion is exact inside one basic block, but at the head
+// of the marching loop (values loaded in one trip, used in the next) it falls
+// back to `s_waitcnt vmcnt(0)`: once per trip every wave drained its whole
+// prefetch queue AND its stores (seen in the ISA of every marching kernel:
+// T=1 with 8 rows in flight, T=12 with 2).  These loads are inline asm, which
+// the compiler neither counts nor waits for; the generator knows the order of
+// all vector-memory instructions of a row step and emits the one wait a step
+// needs itself, `s_waitcnt vmcnt(N)` with N = the number of loads and stores
+// issued after the loads being waited for (they retire in issue order).
+//
+// Rules that make this safe (cdna_hip_programming.md 5.7, form ii):
+//  * a load's destination is a raw 16-byte register group that nothing reads
+//    until it has passed through soda_wait_loads(), which names it "+v" --
+//    consumers cannot be scheduled above the wait;
+//  * the asm statements are volatile with a "memory" clobber: the compiler
+//    keeps them, the stores (builtins) and each other in program order, so
+//    the hand count is the issue order;
+//  * tools/waitcheck.py replays the compiled ISA and fails if any instruction
+//    touches a register group while its load is still in flight (a copy the
+//    register allocator might insert would read stale data).
+// raw register groups: 16 / 8 / <= 4 bytes per lane
+#define SODA_ASM_LOAD(op, dst, r, off, nt)                                 \
+  do {                                                                     \
+    if constexpr (nt)                                                      \
+      asm volatile(op " %0, %1, %2, 0 offen nt"                            \
+                   : "=v"(dst) : "v"(off), "s"(r) : "memory");             \
+    else                                                                   \
+      asm volatile(op " %0, %1, %2, 0 offen"                               \
+                   : "=v"(dst) : "v"(off), "s"(r) : "memory");             \
+  } while (0)
+
+template <int kBytes, bool kNonTemporal>
+SODA_DEV void soda_asm_buf_load(soda_u32x4& dst, soda_rsrc_t r, unsigned off) {
+  static_assert(kBytes == 16, "group size");
+  SODA_ASM_LOAD("buffer_load_dwordx4", dst, r, off, kNonTemporal);
+}
+template <int kBytes, bool kNonTemporal>
+SODA_DEV void soda_asm_buf_load(soda_u32x2& dst, soda_rsrc_t r, unsigned off) {
+  static_assert(kBytes == 8, "group size");
+  SODA_ASM_LOAD("buffer_load_dwordx2", dst, r, off, kNonTemporal);
+}
+template <int kBytes, bool kNonTemporal>
+SODA_DEV void soda_asm_buf_load(unsigned& dst, soda_rsrc_t r, unsigned off) {
+  static_assert(kBytes == 4 || kBytes == 2 || kBytes == 1, "group size");
+  if constexpr (kBytes == 4)
+    SODA_ASM_LOAD("buffer_load_dword", dst, r, off, kNonTemporal);
+  else if constexpr (kBytes == 2)
+    SODA_ASM_LOAD("buffer_load_ushort", dst, r, off, kNonTemporal);
+  else
+    SODA_ASM_LOAD("buffer_load_ubyte", dst, r, off, kNonTemporal);
+}
+
+// raw register group -> (part of a) typed fragment: register renaming, legal
+// only after the group has passed through a wait
+template <class T, int V, class R>
+SODA_DEV void soda_unpack_frag(T (&dst)[V], const R& raw, int group = 0) {
+  constexpr int kBytes = V * (int)sizeof(T);
+  if constexpr (kBytes >= 16) {
+    __builtin_memcpy((char*)dst + 16 * group, &raw, 16);
+  } else if constexpr (kBytes >= 4) {
+    __builtin_memcpy(dst, &raw, kBytes);
+  } else if constexpr (kBytes == 2) {
+    const unsigned short t = (unsigned short)raw;
+    __builtin_memcpy(dst, &t, 2);
+  } else {
+    const unsigned char t = (unsigned char)raw;
+    __builtin_memcpy(dst, &t, 1);
+  }
+}
+
+// `s_waitcnt vmcnt(N)` tied to the register groups it guards
+#define SODA_WAIT_1(n, a) \
+  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a) :: "memory")
+#define SODA_WAIT_2(n, a, b) \
+  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b) :: "memory")
+#define SODA_WAIT_3(n, a, b, c) \
+  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c) :: "memory")
+#define SODA_WAIT_4(n, a, b, c, d)                                         \
+  asm volatile("s_waitcnt vmcnt(" #n ")"                                   \
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+// more groups: further statements that only tie registers (no instruction)
+#define SODA_TIE_1(a) asm volatile("" : "+v"(a) :: "memory")
+#define SODA_TIE_2(a, b) asm volatile("" : "+v"(a), "+v"(b) :: "memory")
+#define SODA_TIE_3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory")
+#define SODA_TIE_4(a, b, c, d) \
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
 
 // ---- stage-pipelined blocks ------------------------------------------------
 // One barrier per row step: every LDS access this wave has issued has

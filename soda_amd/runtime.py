@@ -38,8 +38,8 @@ MAX_KERNELS = 32
 MAX_PASSES = 8
 MAX_PASS_KERNELS = 16
 MAX_PARAMS = 8
-NAME_LEN = 64
-ABI_VERSION = 3
+NAME_LEN = 96
+ABI_VERSION = 4
 
 
 class KernelDesc(ctypes.Structure):
@@ -108,6 +108,7 @@ API = {
         _pi32, _pi32
     ]),
     'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),
+    'soda_hip_program_set_debug_buffer': (ctypes.c_int, [_vp, _vp]),
     'soda_hip_malloc': (ctypes.c_int, [_i32, ctypes.c_size_t, _pvp]),
     'soda_hip_free': (ctypes.c_int, [_i32, _vp]),
     'soda_hip_memcpy_h2d': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
@@ -420,6 +421,89 @@ def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
   return vec
 
 
+def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions'
+                ) -> Dict[int, int]:
+  """{fusion depth: trips of the loop whose warm-up to peel} for the marching
+  kernels of `stencil` under `opts` (MarchConfig.peel).  Peeling skips stages
+  that do not matter yet -- less work per chunk -- but the late, nearly full
+  trips buy little and the straight-line code can need more registers than the
+  loop.  Occupancy decides: per depth, the largest trip count whose COMPILED
+  kernel keeps the waves per SIMD of the unpeeled kernel and spills nothing
+  (jacobi2d T=12: 2 of 4 trips, 158 VGPRs; all 4 would take 231).  Trials are
+  JIT-compiled (no GPU needed) and remembered in the kernel cache."""
+  import copy
+  import json
+  plain = copy.copy(opts)
+  plain.peel = 0
+  mod0 = lower.lower(stencil, plain)
+  todo = {}
+  for k in mod0.kernels:
+    if k.tune and k.tune.get('peel_trips_max'):
+      todo[k.tune['fused']] = k.tune['peel_trips_max']
+  if not todo:
+    return {}
+  key = hashlib.sha256(('peel\0' + '\0'.join(COMPILE_OPTIONS) + '\0' +
+                        mod0.source).encode()).hexdigest()[:24]
+  memo = os.path.join(CACHE_DIR, 'peel_%s.json' % key)
+  try:
+    with open(memo) as f:
+      return {int(t): int(v) for t, v in json.load(f).items()}
+  except (OSError, ValueError):
+    pass
+
+  def probe(depth: int, trips: int):
+    one = copy.copy(opts)
+    one.fuse = (depth,) if depth > 1 else ()
+    one.peel = trips
+    mod = lower.lower(stencil, one)
+    res = kernel_resources(compile_source(mod.source,
+                                          '%s.hip' % stencil.app_name))
+    for k in mod.kernels:
+      if k.tune and k.tune.get('fused') == depth:
+        r = res.get(k.name)
+        return None if not r else (waves_per_simd(r['vgpr']), r['scratch'])
+    return None
+
+  chosen = {}
+  for depth, most in todo.items():
+    base = probe(depth, 0)
+    chosen[depth] = 0
+    if base is None:
+      continue
+    for trips in range(most, 0, -1):
+      got = probe(depth, trips)
+      if got is not None and got[0] >= base[0] and got[1] <= base[1]:
+        chosen[depth] = trips
+        break
+  try:
+    os.makedirs(CACHE_DIR, exist_ok=True)
+    tmp = '%s.%d.tmp' % (memo, os.getpid())
+    with open(tmp, 'w') as f:
+      json.dump(chosen, f)
+    os.replace(tmp, memo)
+  except OSError:
+    pass
+  return chosen
+
+
+def resolve_options(stencil: core.Stencil,
+                    opts: Optional['lower.LowerOptions'],
+                    extent: Optional[Sequence[int]]) -> 'lower.LowerOptions':
+  """A private copy of the caller's options with everything this module
+  decides filled in: the vector width for `extent`, the peel depths."""
+  import copy
+  out = copy.copy(opts) if opts is not None else lower.LowerOptions()
+  if out.vec is None:
+    out.vec = pick_vec(stencil, extent)
+  if out.peel is None and out.strategy in ('auto', 'march') and \
+      lower.march_supported(stencil) is None:
+    try:
+      out.peel = select_peel(stencil, out)
+    except util.SemanticError:
+      out.peel = 0
+  return out
+
+
 class Program:
   """A SODA program JIT-built for gfx950 and loaded on one GPU."""
 
@@ -427,9 +511,7 @@ class Program:
                opts: Optional[lower.LowerOptions] = None, device: int = 0,
                extent: Optional[Sequence[int]] = None):
     self.stencil = stencil
-    self.opts = opts or lower.LowerOptions()
-    if self.opts.vec is None:
-      self.opts.vec = pick_vec(stencil, extent)
+    self.opts = resolve_options(stencil, opts, extent)   # never the caller's
     self.device = device
     self.module = lower.lower(stencil, self.opts)
     self.plan = make_plan(self.module)
@@ -538,6 +620,12 @@ class Program:
                                              gext, iterate,
                                              ctypes.c_void_p(stream)),
         'running `%s`' % st.app_name)
+
+  def set_debug_buffer(self, ptr: int) -> None:
+    """Device buffer the time stamps of `stamps=True` kernels go to."""
+    check(self._lib.soda_hip_program_set_debug_buffer(self._handle,
+                                                      ctypes.c_void_p(ptr)),
+          'set_debug_buffer')
 
   def last_launches(self):
     a, b = ctypes.c_int32(), ctypes.c_int32()

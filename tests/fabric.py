@@ -1,0 +1,99 @@
+"""In-process stand-in for torch.distributed's point-to-point calls (TEST
+INFRASTRUCTURE): N ranks are N threads of one process, a message is a tensor
+copy handed over through a queue.  `Fabric.endpoint(rank)` quacks like the
+`dist_module` argument of soda_amd.dist.exchange/run (P2POp, isend, irecv,
+batch_isend_irecv, barrier), so a multi-rank slab run -- every rank executing
+the REAL decomposition, exchange schedule and kernels -- can be rehearsed on
+the single GPU of a test box, where RCCL needs one device per rank."""
+import queue
+import threading
+from typing import List
+
+TIMEOUT_S = 300
+
+
+class _Recv:
+
+  def __init__(self, q: 'queue.Queue', tensor):
+    self.q, self.tensor = q, tensor
+
+  def wait(self) -> None:
+    self.tensor.copy_(self.q.get(timeout=TIMEOUT_S))
+
+
+class _Done:
+
+  def wait(self) -> None:
+    pass
+
+
+class Endpoint:
+  isend = 'isend'
+  irecv = 'irecv'
+
+  def __init__(self, fabric: 'Fabric', rank: int):
+    self.fabric, self.rank = fabric, rank
+    self.messages = 0
+    self.bytes = 0
+
+  @staticmethod
+  def P2POp(op, tensor, peer, group=None):
+    return (op, tensor, peer)
+
+  def batch_isend_irecv(self, ops) -> List:
+    reqs = []
+    for op, tensor, peer in ops:      # sends first: they never block
+      if op == self.isend:
+        self.fabric.q[(self.rank, peer)].put(tensor.clone())
+        self.messages += 1
+        self.bytes += tensor.numel() * tensor.element_size()
+        reqs.append(_Done())
+    for op, tensor, peer in ops:
+      if op == self.irecv:
+        reqs.append(_Recv(self.fabric.q[(peer, self.rank)], tensor))
+    return reqs
+
+  def barrier(self) -> None:
+    self.fabric.barrier_obj.wait(timeout=TIMEOUT_S)
+
+  def get_world_size(self) -> int:
+    return self.fabric.world
+
+  def get_rank(self) -> int:
+    return self.rank
+
+
+class Fabric:
+
+  def __init__(self, world: int):
+    self.world = world
+    self.q = {(s, d): queue.Queue()
+              for s in range(world) for d in range(world) if s != d}
+    self.barrier_obj = threading.Barrier(world)
+
+  def endpoint(self, rank: int) -> Endpoint:
+    return Endpoint(self, rank)
+
+
+def run_ranks(world: int, fn) -> list:
+  """Runs fn(rank, endpoint) on `world` threads; returns the results in rank
+  order, re-raising the first exception."""
+  fabric = Fabric(world)
+  results = [None] * world
+  errors = []
+
+  def body(rank):
+    try:
+      results[rank] = fn(rank, fabric.endpoint(rank))
+    except BaseException as e:  # noqa: surface it in the caller's thread
+      errors.append(e)
+      fabric.barrier_obj.abort()
+
+  threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  if errors:
+    raise errors[0]
+  return results

@@ -72,13 +72,13 @@ def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
   assert code[:4] == b'\x7fELF'
   for k in mod.kernels:
     assert k.name.encode() in code
-  # 17 x 17 taps: too many lane-shifted operands per row for register windows
-  direct_only = ('contrast.soda',)
-  if name in direct_only:
-    assert all(p.kind == 'direct' for p in mod.passes)
-  elif stencil.dim == 2:
+  # (contrast: 17 x 17 taps; as the reference really evaluates it -- seven
+  # stages of <= 32 taps after `inline.rebalance` -- it fits register windows
+  # at one cell per lane)
+  if stencil.dim == 2:
     assert all(p.kind == 'march2d' for p in mod.passes)
-    assert sorted(p.fused_iters for p in mod.passes) == sorted({1} | set(fuse))
+    if name != 'contrast.soda':    # (three fused iterations of it do not fit)
+      assert sorted(p.fused_iters for p in mod.passes) == sorted({1} | set(fuse))
   else:
     assert all(p.kind == 'march3d' for p in mod.passes)
     assert max(p.fused_iters for p in mod.passes) <= lower.MAX_FUSE_3D

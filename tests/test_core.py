@@ -167,3 +167,74 @@ def test_stage_order_follows_dependences_not_file_order():
   # ... but the box also keeps every LOADED element in the grid (the element
   # second(0,0) reads, first(0,1), exists only where 0 is in range too)
   assert s.window_bounds()['o'] == ((0, 0), (1, 1))
+
+
+def test_rebalance_of_contrast_known_answer():
+  """`inline.rebalance` (ref src/soda/optimization/inline.py:175-262, always
+  run from core.py:138) on the one corpus program it touches, derived by hand
+  from the text of contrast.soda: its 197 terms come in rows of 1, 7, 11, 13,
+  13, 15, 15, 17, 17, 15, 15, 13, 13, 11, 7, 1+... taps; 32-term groups in
+  textual order end after the rows' running totals 32, 64, ... ; six locals
+  cr_var_0..5 (ref core.py:183-191 naming) and a 5-term remainder."""
+  from conftest import soda_path
+  from soda_amd import ir
+  st = core.from_file(soda_path('contrast.soda'))
+  assert st.local_names == tuple('cr_var_%d' % i for i in range(6))
+  assert all(str(t) == 'float' for t in st.local_types)
+  bare = lambda e: e.expr if isinstance(e, ir.Cast) else e
+  groups = [bare(s.expr) for s in st.local_stmts]
+  assert [len(g.operands) for g in groups] == [32] * 6
+  assert all(set(g.operators) == {'+'} for g in groups)
+  # first and last term of every group, counted off the program text:
+  # rows hold 1, 7, 11, 13 (=32) | 13, 15, +4 of row 6 (=32) | ...
+  ends = [('input(8, 0) * -106', 'input(14, 3) * -98'),
+          ('input(2, 4) * -73', 'input(4, 6) * 37'),
+          ('input(5, 6) * 67', 'input(5, 8) * 84')]
+  for g, (first, last) in zip(groups, ends):
+    assert (str(g.operands[0]), str(g.operands[-1])) == (first, last)
+  assert all(s.ref.idx == (0, 0) for s in st.local_stmts)
+  out = bare(st.output_stmts[0].expr)
+  assert len(out.operands) == 5 + 6 and set(out.operators) == {'+'}
+  assert [str(o) for o in out.operands[5:]] == [
+      'cr_var_%d(0, 0)' % i for i in range(6)]
+  assert str(out.operands[4]) == 'input(8, 16) * -106'
+  # windows: the output still spans the whole 17 x 17 footprint
+  assert st.window_bounds(1)['output'] == ((0, 0), (16, 16))
+
+
+@pytest.mark.parametrize('name', ['jacobi2d', 'blur', 'heat3d', 'sobel2d',
+                                  'seidel2d', 'denoise2d', 'denoise3d',
+                                  'erosion', 'xcorr', 'jacobi3d'])
+def test_rebalance_leaves_the_rest_of_the_corpus_alone(name):
+  """No other corpus program has an fp32 `+` chain of more than 32 terms."""
+  from conftest import soda_path
+  st = core.from_file(soda_path(name + '.soda'))
+  assert not any(n.startswith('cr_var_') for n in st.local_names)
+
+
+def test_rebalance_groups_by_item_count():
+  """Terms `coeff * (a + b + ...)` count as their inner length, are sorted
+  largest first (stably) and rebuilt as `(a + b + ...) * coeff` (ref
+  inline.py:191-203, :228-233)."""
+  inner = lambda k, n: ' + '.join('a(%d, %d)' % (i, k) for i in range(n))
+  text = '''kernel: t
+burst width: 64
+unroll factor: 2
+iterate: 1
+input dram 0 float: a(64, *)
+output dram 1 float: b(0, 0) = a(0, 9) + 2.0f * (%s) + (%s) * 3.0f + a(1, 9)
+''' % (inner(0, 20), inner(1, 30))
+  st = core.from_text(text)
+  # items 1, 20, 30, 1 -> sorted 30, 20, 1, 1 -> groups [30] and [20, 1, 1]
+  # (30 + 20 > 32 opens the second group; 20 + 1 + 1 fits): ONE new local
+  from soda_amd import ir
+  bare = lambda e: e.expr if isinstance(e, ir.Cast) else e
+  assert st.local_names == ('cr_var_0',)
+  first = bare(st.local_stmts[0].expr)
+  assert first.operators == ('*',) and str(first.operands[1]) == '3.0f'
+  assert len(first.operands[0].operands) == 30
+  out = bare(st.output_stmts[0].expr)
+  assert [len(getattr(o, 'operands', ())) for o in out.operands] == [2, 0, 0, 0]
+  assert str(out.operands[0].operands[1]) == '2.0f'       # coefficient last
+  assert [str(o) for o in out.operands[1:]] == [
+      'a(0, 9)', 'a(1, 9)', 'cr_var_0(0, 0)']

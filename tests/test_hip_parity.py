@@ -116,6 +116,72 @@ extern "C" __global__ void probe(soda_hip_kargs_t a) {
   assert (out[192:] == np.where(lane < 63, 2 * lane + 3, 0)).all()
 
 
+def _probe(src, name, n_out):
+  """Runs a one-block probe kernel `name(kargs)` that fills n_out ints."""
+  from soda_amd import runtime
+  code = runtime.compile_source(src, name + '.hip')
+  plan = runtime.Plan()
+  plan.abi_version = runtime.ABI_VERSION
+  plan.dim = 1
+  plan.num_inputs = plan.num_outputs = 1
+  plan.elem_size[0] = plan.elem_size[1] = 4
+  plan.num_kernels = 1
+  plan.kernels[0].name = name.encode()
+  plan.kernels[0].block[0] = 64
+  plan.kernels[0].block[1] = plan.kernels[0].block[2] = 1
+  plan.kernels[0].tile[0] = n_out
+  plan.num_passes = 1
+  plan.passes[0].fused_iters = 1
+  plan.passes[0].num_kernels = 1
+  lib = runtime.library()
+  handle = ctypes.c_void_p()
+  runtime.check(lib.soda_hip_program_create(code, len(code), ctypes.byref(plan),
+                                            0, ctypes.byref(handle)), 'create')
+  a = np.zeros(n_out, np.int32)
+  out = np.full(n_out, -1, np.int32)
+  ext = (ctypes.c_int32 * 1)(n_out)
+  strd = (ctypes.c_int32 * 1)(1)
+  tin = (runtime.HostTensor * 1)(runtime.HostTensor(a.ctypes.data, ext, strd,
+                                                    None))
+  tout = (runtime.HostTensor * 1)(runtime.HostTensor(out.ctypes.data, ext,
+                                                     strd, None))
+  runtime.check(lib.soda_hip_run_host(handle, tin, tout, 1), 'run')
+  lib.soda_hip_program_destroy(handle)
+  return out
+
+
+def test_swizzle_lane_shift_direction(built):
+  """The ds_swizzle rotate forms of soda_rt.h move data the way
+  codegen/hip/march.py assumes: *32 rotate inside each 32-lane half, *64 shift
+  the whole wave (lane 0 of `dn` / lane 63 of `up` hold a wrapped value: halo
+  lanes)."""
+  from soda_amd.codegen.hip import lower
+  src = lower.runtime_text() + '''
+extern "C" __global__ void swzprobe(soda_hip_kargs_t a) {
+  int* out = (int*)a.buf[1];
+  const int lane = threadIdx.x;
+  out[lane] = soda_lane_dn32(lane + 100);
+  out[64 + lane] = soda_lane_up32(lane + 100);
+  out[128 + lane] = soda_lane_dn64(lane + 100);
+  out[192 + lane] = soda_lane_up64(lane + 100);
+  out[256 + lane] = (int)soda_lane_dn64((uint16_t)(lane + 7));
+  out[320 + lane] = (int)(soda_lane_up64((double)lane + 0.5) * 2.0);
+  out[384 + lane] = (int)soda_lane_dn32((float)lane);
+}
+'''
+  out = _probe(src, 'swzprobe', 448)
+  lane = np.arange(64)
+  half = lane & 32
+  msg = 'dn32 %s\nup32 %s' % (out[:64].tolist(), out[64:128].tolist())
+  assert (out[:64] == 100 + (half | ((lane - 1) & 31))).all(), msg
+  assert (out[64:128] == 100 + (half | ((lane + 1) & 31))).all(), msg
+  assert (out[129:192] == lane[1:] + 99).all(), out[128:192].tolist()
+  assert (out[192:255] == lane[:63] + 101).all(), out[192:256].tolist()
+  assert (out[257:320] == lane[1:] + 6).all()
+  assert (out[320:383] == 2 * lane[:63] + 3).all()
+  assert (out[384:448] == (half | ((lane - 1) & 31))).all()
+
+
 CORPUS_2D = ['jacobi2d.soda', 'blur.soda', 'seidel2d.soda', 'sobel2d.soda',
              'denoise2d.soda', 'skew2d.soda', 'erosion.soda', 'xcorr.soda',
              'contrast.soda']

@@ -339,3 +339,114 @@ def test_param_reference_errors(bad, why):
           'output float: b(0, 0) = a(0, 0) * %s\n' % bad)
   with pytest.raises(util.SemanticError, match=why):
     core.from_text(text)
+
+
+# ---------------------------------------------------------------------------
+# the rest of the reference's 2-D corpus against hand-written loop nests
+# (oracle/kat_kernels.c: written from the DSL text, never through
+# soda_amd.grammar / core / ir)
+# ---------------------------------------------------------------------------
+
+def _i16(rng, shape, lo=-120, hi=120):
+  return rng.integers(lo, hi, shape).astype(np.int16)
+
+
+def _corpus_kat(kat, name, rng):
+  """(inputs by DSL name, expected output by DSL name) from the hand-written
+  kernel of corpus program `name`."""
+  shape = (30, 44)                # 44 columns (dim 0), 30 rows
+  h, w = shape
+  if name == 'sobel2d':
+    img = _i16(rng, shape)
+    out = np.empty(shape, np.uint16)
+    assert kat.kat_sobel2d(_ptr(img), _ptr(out), w, h) == 0
+    return {'img': img}, {'mag': out}
+  if name == 'seidel2d':
+    a = rng.random(shape, dtype=np.float32)
+    out = np.empty_like(a)
+    assert kat.kat_seidel2d(_ptr(a), _ptr(out), w, h, 2) == 0
+    return {'input': a}, {'output': out}
+  if name == 'denoise2d':
+    f = rng.random(shape, dtype=np.float32)
+    u = rng.random(shape, dtype=np.float32)
+    out = np.empty_like(f)
+    assert kat.kat_denoise2d(_ptr(f), _ptr(u), _ptr(out), w, h) == 0
+    return {'f': f, 'u': u}, {'output': out}
+  if name == 'erosion':
+    a = _i16(rng, shape, -30000, 30000)
+    out = np.empty_like(a)
+    assert kat.kat_erosion(_ptr(a), _ptr(out), w, h) == 0
+    return {'input': a}, {'output': out}
+  if name == 'xcorr':
+    a = _i16(rng, shape, -3000, 3000)
+    out = np.empty_like(a)
+    assert kat.kat_xcorr(_ptr(a), _ptr(out), w, h) == 0
+    return {'input': a}, {'tmp3': out}
+  raise KeyError(name)
+
+
+@pytest.mark.parametrize('name', ['sobel2d', 'seidel2d', 'denoise2d',
+                                  'erosion', 'xcorr'])
+def test_corpus_against_hand_written_kernels(kat, name):
+  """Front-end + both generated oracles against an independent reading of the
+  program text, bit for bit on the valid box; zero outside it."""
+  from oracle import c_oracle, numpy_oracle
+  st = core.from_file(soda_path(name + '.soda'))
+  ins, want = _corpus_kat(kat, name, np.random.default_rng(99))
+  got_np = numpy_oracle.run(st, ins)
+  got_c = c_oracle.COracle(st).run(ins)
+  for o, w in want.items():
+    lo, hi = st.valid_box(w.shape[::-1], o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert w[idx].any(), 'degenerate test data'
+    assert np.array_equal(got_np[o][idx], w[idx])
+    assert np.array_equal(got_c[o][idx], w[idx])
+    outside = np.ones(w.shape, bool)
+    outside[idx] = False
+    assert not w[outside].any()       # the hand-derived box IS the valid box
+
+
+def _contrast_taps():
+  """(dx, dy, coef) of every term of contrast.soda, read from the DSL text by
+  a regular expression (not by this repo's parser)."""
+  import re
+  with open(soda_path('contrast.soda')) as f:
+    text = f.read()
+  taps = re.findall(r'input\s*\(\s*(-?\d+)\s*,\s*(-?\d+)\s*\)\s*\*\s*(-?\d+)', text)
+  return [tuple(map(int, t)) for t in taps]
+
+
+def test_contrast_follows_the_reference_rebalance(kat):
+  """contrast.soda is a 197-term fp32 sum; the reference's always-on
+  `inline.rebalance` (inline.py:175-262) evaluates it as six 32-term locals
+  plus a 5-term remainder.  The hand-written kernel restates that association;
+  front-end + oracles must equal it bit for bit -- and must NOT equal the
+  plain left-to-right sum of the program text."""
+  from oracle import c_oracle, numpy_oracle
+  taps = _contrast_taps()
+  assert len(taps) == 197
+  dx, dy, cf = (np.array(v, np.int32) for v in zip(*taps))
+  rng = np.random.default_rng(5)
+  a = rng.random((40, 56), dtype=np.float32)
+  h, w = a.shape
+  want = np.empty_like(a)
+  assert kat.kat_rebalanced_sum(_ptr(a), _ptr(want), w, h, len(taps), _ptr(dx),
+                                _ptr(dy), _ptr(cf), 32) == 0
+  plain = np.empty_like(a)
+  assert kat.kat_rebalanced_sum(_ptr(a), _ptr(plain), w, h, len(taps), _ptr(dx),
+                                _ptr(dy), _ptr(cf), 1000) == 0
+  st = core.from_file(soda_path('contrast.soda'))
+  lo, hi = st.valid_box((w, h))
+  assert (lo, hi) == ((0, 0), (w - 16, h - 16))
+  idx = (slice(lo[1], hi[1]), slice(lo[0], hi[0]))
+  got_np = numpy_oracle.run(st, {'input': a})['output']
+  got_c = c_oracle.COracle(st).run({'input': a})['output']
+  assert np.array_equal(got_np[idx], want[idx])
+  assert np.array_equal(got_c[idx], want[idx])
+  assert not np.array_equal(plain[idx], want[idx])
+  # The association is not a detail: the coefficients sum to ~0, the terms
+  # cancel, and on uniform [0, 1) data the plain left-to-right sum FAILS the
+  # reference's own compare rule (frt/host.py:634-657, 1e-5) against the
+  # rebalanced sum in dozens of cells.  Any re-associated evaluation -- an
+  # MFMA fma chain included (SURVEY 8 f3) -- is in the same position.
+  assert numpy_oracle.compare(plain, want, lo, hi) >= 10
