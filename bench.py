@@ -39,7 +39,7 @@ def parse_args():
       ROOT, 'tests', 'golden', 'soda', 'jacobi2d.soda'))
   ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])
   ap.add_argument('--iterate', type=int, default=100)
-  ap.add_argument('--fuse', type=int, nargs='+', default=[12, 4],
+  ap.add_argument('--fuse', type=int, nargs='+', default=[12, 8, 4],
                   help='iterations fused per launch (temporal blocking); the '
                   'first value is the dominant pass, the others serve the '
                   'remainder of iterate')
@@ -210,8 +210,10 @@ def main():
     slab.world = 1   # no peers: exchange() is a no-op
   local_extent = slab.local_extent
 
+  # calibrate: the library times one launch of every pass on this rank's
+  # extent and schedules the iterations by the clock (soda_hip_program_calibrate)
   prog = runtime.Program(stencil, options(fuses), device=local_rank,
-                         extent=local_extent)
+                         extent=local_extent, calibrate=True)
   stream = torch.cuda.current_stream().cuda_stream
 
   # synthetic input: the same seeded global field on every rank, sliced
@@ -247,15 +249,15 @@ def main():
   # iterate); the arrays rotate through the pool and the array that holds the
   # state is never written while it is read.
   pool = [a_bufs, b_bufs] + ([c_bufs] if c_bufs else [])
-  state = {'cur': a_bufs, 'first': True}
+  chain = {'cur': a_bufs, 'first': True}
 
   def one_step():
-    cur = state['cur']
+    cur = chain['cur']
     others = [x for x in pool if x is not cur]
     res = sdist.run(slab, cur, others[0], others[-1], step_fn, args.iterate,
-                    tdist, ghosts_fresh=state['first'] or world == 1)
-    state['first'] = False
-    state['cur'] = next(x for x in pool if x[0] is res[0])
+                    tdist, ghosts_fresh=chain['first'] or world == 1)
+    chain['first'] = False
+    chain['cur'] = next(x for x in pool if x[0] is res[0])
     return res
 
   def barrier():
@@ -432,6 +434,11 @@ def main():
           'ghost_row_fraction': (slab.rows - slab.own_rows) / float(slab.rows),
           'launches_per_step': launches_per_step,
           'passes': [p.fused_iters for p in prog.module.sorted_passes()],
+          'schedule_per_exchange_interval': {
+              str(t): c for t, c in prog.schedule(
+                  local_extent, min(ex, args.iterate)).items()},
+          'pass_us_measured': {str(t): round(v, 1) for t, v in
+                               prog.pass_times(local_extent)[0].items()},
       },
       'roofline': roofline,
   }

@@ -92,7 +92,40 @@ typedef struct soda_hip_kernel_desc {
   int32_t block[3];                    /* threads per block */
   int32_t tile[SODA_HIP_MAX_DIM];      /* output cells one block owns, per dim */
   int32_t lds_bytes;                   /* dynamic LDS */
-  int32_t reserved;
+  /* What the library needs to check a launch and to shape it for the extent
+   * it is given at RUN time (the reference bakes tile sizes into its kernel
+   * at compile time, hls_kernel.py:30-202; here only the code is fixed, the
+   * launch geometry is not).  All zero: a kernel with a fixed tile and no
+   * constraint. */
+  int32_t vec;                         /* cells per lane: extent[0] must be a
+                                          multiple (0 / 1: any) */
+  int32_t march_dim;                   /* 1 + the dimension a marching kernel
+                                          streams along (its tile there is the
+                                          chunk, a run-time value); 0: none */
+  int32_t waves_along;                 /* waves of a block along that dimension */
+  int32_t warm;                        /* row steps of pipeline warm-up a chunk
+                                          pays on top of its own rows */
+  int32_t window_extra;                /* buffer addressing: planes beyond the
+                                          chunk one wave's window spans; the
+                                          window must stay <= 1 GiB.  -1: plain
+                                          pointers, no limit */
+  int32_t max_elem;                    /* bytes of the widest element so addressed */
+  int32_t vgprs;                       /* registers per lane of the compiled
+                                          kernel (occupancy); 0: unknown, the
+                                          tile is used as given */
+  int32_t pipe;                        /* waves sharing the fused iterations */
+  int32_t chunk_fixed;                 /* 1: never re-size the chunk */
+  /* time model of one launch, used to pick the chunk and, per pass, the
+   * multiset of passes that advances `iterate` iterations fastest on THIS
+   * extent:  max(k * (chunk + warm - warm_saved) * step_ns, bytes / HBM rate)
+   * with k = waves per SIMD the grid needs */
+  float step_ns;                       /* one row step of one wave, ns of SIMD
+                                          issue time; 0: memory time only */
+  float warm_saved;                    /* row steps' worth of work the peeled
+                                          warm-up skips */
+  float bytes_per_cell;                /* HBM bytes per cell per launch (inputs
+                                          + outputs), before halo re-reads */
+  float lane_redundancy;               /* lanes of a strip / lanes that store */
 } soda_hip_kernel_desc_t;
 
 /* One way of advancing the program by `fused_iters` iterations: the listed
@@ -102,7 +135,9 @@ typedef struct soda_hip_pass_desc {
   int32_t num_kernels;
   int32_t kernel[SODA_HIP_MAX_PASS_KERNELS];
   float cost;                          /* relative time of one such pass (any
-                                          unit); <= 0 in every pass: schedule
+                                          unit) where the kernels carry no time
+                                          model (step_ns and bytes_per_cell all
+                                          zero); <= 0 in every pass: schedule
                                           greedily, deepest first */
 } soda_hip_pass_desc_t;
 
@@ -150,6 +185,22 @@ int soda_hip_compile(const char* source, const char* name,
                      const char* const* options, int32_t num_options,
                      void** code, size_t* code_size);
 void soda_hip_free_code(void* code);
+
+/* -- launch geometry (pure functions of the plan: no GPU, no program) ------- */
+/* What a run on `extent` would use: the tile of every kernel (num_kernels x
+ * SODA_HIP_MAX_DIM values; chunk lengths sized so the grid fills the 1024
+ * SIMDs of an MI355X in whole rounds of equally loaded waves) and the modelled
+ * time of every pass in nanoseconds (num_passes values; 0 where the kernels
+ * carry no model).  Fails with SODA_HIP_ERR_INVALID -- text in last_error --
+ * if a kernel cannot run this extent: rows that are not a multiple of its
+ * vector width, a plane too large for its 1 GiB buffer window.  Either output
+ * may be NULL. */
+int soda_hip_plan_geometry(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t* tiles, float* pass_ns);
+/* How many times each pass runs to advance `iterate` iterations on `extent`
+ * (num_passes values): the multiset of least total modelled time. */
+int soda_hip_plan_schedule(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t iterate, int32_t* count);
 
 /* -- program = code object + plan, bound to one device -------------------- */
 int soda_hip_program_create(const void* code, size_t code_size,
@@ -204,6 +255,26 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi);
 
+/* Measures one launch of every pass on `extent` (stand-in arrays, `launches`
+ * back-to-back launches per pass, HIP events on `stream`; synchronises) and
+ * remembers the times: later runs on exactly this extent schedule their passes
+ * by the clock instead of the model.  Costs a few milliseconds once; programs
+ * with a single pass have nothing to choose and return at once. */
+int soda_hip_program_calibrate(soda_hip_program_t* program,
+                               const int32_t* extent, int32_t launches,
+                               void* stream);
+/* Time of one launch of every pass on `extent` in ns (num_passes values):
+ * measured if calibrated (*measured = 1), else the model's. */
+int soda_hip_program_pass_times(soda_hip_program_t* program,
+                                const int32_t* extent, float* pass_ns,
+                                int32_t* measured);
+
+/* The schedule a run of `iterate` iterations on `extent` uses (num_passes
+ * counts), from measured times where calibrated. */
+int soda_hip_program_schedule(soda_hip_program_t* program,
+                              const int32_t* extent, int32_t iterate,
+                              int32_t* count);
+
 /* Diagnostics: kernels generated with time stamps (sodac --hip-stamps) write
  * four 64-bit words per wavefront -- s_memtime at entry and exit, HW_ID,
  * XCC_ID -- to this device buffer (slot SODA_HIP_MAX_TENSORS - 1 of the kernel
@@ -215,6 +286,72 @@ int soda_hip_program_set_debug_buffer(soda_hip_program_t* program, void* buf);
  * many of them used the pass with the largest fused_iters. */
 int soda_hip_last_launches(soda_hip_program_t* program, int32_t* launches,
                            int32_t* fused_launches);
+
+/* -- the reference kernel's WIRE format: <app>_kernel on banked streams -----
+ * The reference's generated host hands its kernel one linear stream per
+ * tensor -- tiles end to end, each padded to whole bursts, elements dealt
+ * cyclically over the tensor's DRAM banks, kStencilDistance void elements
+ * appended (src/soda/codegen/frt/host.py:124-249, docs/data-layout.md) -- and
+ * calls
+ *     <app>_kernel(bank_0_<out>..., bank_0_<in>..., coalesced_data_num)
+ * (frt/host.py:44-59 declaration, :282-289 call; outputs first).  A stream
+ * object runs exactly that contract on the GPU, so the unmodified generated
+ * host can link against it under SODA_CPP_BINDING (`sodac --hip-wire-kernel`
+ * prints the extern "C" <app>_kernel definition that calls it).  Per call:
+ * un-interleave the inputs (skipped for single-bank inputs, read in place),
+ * run the program on the de-interleaved stream -- as the original n-D program
+ * with the marching kernels when the stream is a dense array of rows, else as
+ * the linearised 1-D program -- and write the outputs back shifted by their
+ * stencil offset (frt/host.py:400-424) and re-interleaved. */
+typedef struct soda_hip_stream_desc {
+  int32_t dim;                         /* of the original program */
+  int32_t num_inputs;
+  int32_t num_outputs;
+  int32_t iterate;
+  int32_t tile[SODA_HIP_MAX_DIM];      /* tile size of dimensions 0..dim-2 */
+  int32_t stencil_distance;            /* kStencilDistance (frt/host.py:683-696) */
+  /* per tensor, inputs first, then outputs */
+  int32_t banks[SODA_HIP_MAX_TENSORS];
+  int32_t elem_size[SODA_HIP_MAX_TENSORS];
+  int32_t elems_per_cycle[SODA_HIP_MAX_TENSORS];  /* burst width / element
+                                          width x banks (frt/host.py:120-122) */
+  int32_t shift[SODA_HIP_MAX_TENSORS]; /* inputs: produce offset the host delays
+                                          the tensor by (frt/host.py:241-246);
+                                          outputs: stencil offset the kernel
+                                          emits a cell late by (:401-408) */
+  int32_t num_linear;                  /* 1-D programs offered, widest first */
+  int32_t linear_vec[4];               /* their cells per thread; the last is 1 */
+} soda_hip_stream_desc_t;
+
+typedef struct soda_hip_stream soda_hip_stream_t;      /* opaque */
+
+/* `dense`: the original program (NULL: always the linear form); `linear`:
+ * num_linear programs of the linearised 1-D form; `unwire[i]` / `wire[o]`: the
+ * copy kernels of input i / output o as one-kernel programs (unwire[i] may be
+ * NULL for an input with one bank and no shift).  The stream borrows the
+ * programs; the caller destroys them after the stream. */
+int soda_hip_stream_create(const soda_hip_stream_desc_t* desc,
+                           soda_hip_program_t* dense,
+                           soda_hip_program_t* const* linear,
+                           soda_hip_program_t* const* unwire,
+                           soda_hip_program_t* const* wire,
+                           soda_hip_stream_t** stream);
+int soda_hip_stream_destroy(soda_hip_stream_t* stream);
+/* Bank pointers in the order of the reference kernel's ports: all banks of
+ * output 0, output 1, ...; then all banks of input 0, input 1, ....  Device
+ * pointers, asynchronous on `hip_stream`. */
+int soda_hip_stream_run_device(soda_hip_stream_t* stream,
+                               void* const* out_banks,
+                               const void* const* in_banks,
+                               uint64_t coalesced_data_num, void* hip_stream);
+/* The same on host buffers sized as the reference host allocates them
+ * (coalesced_data_num x elems_per_cycle / banks elements per bank): what
+ * <app>_kernel receives under SODA_CPP_BINDING.  Synchronous. */
+int soda_hip_stream_run_host(soda_hip_stream_t* stream, void* const* out_banks,
+                             const void* const* in_banks,
+                             uint64_t coalesced_data_num);
+/* 1: the last run used the dense n-D form, 2: the linear form, 0: none yet */
+int soda_hip_stream_last_mode(soda_hip_stream_t* stream);
 
 /* -- device memory and timing helpers for hosts without their own -------- */
 int soda_hip_malloc(int32_t device, size_t bytes, void** ptr);

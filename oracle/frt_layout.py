@@ -6,8 +6,9 @@ src/soda/codegen/frt/host.py:124-178), scatter of the caller's array into
 tiled, burst-aligned, bank-interleaved streams (:181-249) and gather of each
 output's valid region (:340-427).  It lets tests drive
 soda_amd.stream.StreamProgram exactly the way the unmodified reference host
-would.  Only single-input programs are covered (`produce_offset` of further
-inputs comes out of the reference's ILP).  For several tiles the reference
+would.  Further inputs are delayed by their `produce_offset` exactly as the
+host does (:241-246); the offsets come from soda_amd.core's restatement of the
+reference's ILP (Stencil.produce_offsets).  For several tiles the reference
 scatters with stride `tile - kStencilDim` (:225-227) but gathers with
 `tile - kStencilDim + 1` (:389-391), so what the caller gets back is not the
 n-D stencil of its array; multi-tile tests therefore compare against
@@ -66,9 +67,16 @@ def scatter(layout, inputs):
     orig = [tidx[d] * (tile[d] - layout.stencil_dim[d]) + grids[d]
             for d in range(dim - 1)] + [grids[dim - 1]]
     tiled = tile_lin * layout.aligned_per_tile_i + off_in_tile
+    # data[max(0, original_offset - produce_offset)]   (host.py:241-246)
+    orig_lin = np.zeros_like(grids[0])
+    mul = 1
+    for d in range(dim):
+      orig_lin = orig_lin + orig[d] * mul
+      mul *= layout.extent[d]
+    delays = st.produce_offsets()
     for name in st.input_names:
       nb = layout.bank_count[name]
-      vals = inputs[name][tuple(orig[::-1])]
+      vals = inputs[name].ravel()[np.maximum(0, orig_lin - delays[name])]
       for b in range(nb):
         sel = (tiled % nb) == b
         banks[name][b][(tiled[sel] // nb)] = vals[sel]
@@ -133,6 +141,9 @@ def kernel_on_streams(layout, in_banks):
     s = np.zeros(n, in_banks[name][0].dtype)
     for b in range(nb):
       s[b::nb] = in_banks[name][b][:len(s[b::nb])]
+    po = st.produce_offsets()[name]      # the host delayed this tensor
+    if po:
+      s = np.concatenate([s[po:], np.zeros(po, s.dtype)])
     streams[name] = s
   out1d = numpy_oracle.run(stream.linearize(st), streams)
   out_banks = alloc(layout, st.output_names)

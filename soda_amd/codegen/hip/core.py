@@ -31,6 +31,12 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-host', type=str, dest='hip_host', metavar='file',
                       help='C++ host: soda::app::<app>() with the signature '
                       'of --frt-host, on libsoda_hip.so')
+  parser.add_argument('--hip-wire-kernel', type=str, dest='hip_wire_kernel',
+                      metavar='file', help='C++ definition of extern "C" '
+                      '<app>_kernel(banks..., coalesced_data_num) -- the '
+                      "reference kernel's ABI on its tiled, banked streams -- "
+                      'on libsoda_hip.so: links under the unmodified '
+                      '--frt-host output built with -DSODA_CPP_BINDING')
   parser.add_argument('--hip-backend', action='store_true', dest='hip_backend',
                       help='JIT-build the HIP kernels and run them on the GPU')
   parser.add_argument('--hip-strategy', type=str, dest='hip_strategy',
@@ -111,6 +117,14 @@ def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
       sys.stdout.write(text)
     else:
       with open(args.hip_host, 'w') as f:
+        f.write(text)
+  if getattr(args, 'hip_wire_kernel', None) is not None:
+    from soda_amd.codegen.hip import wire
+    text = wire.print_wire_kernel(stencil)
+    if args.hip_wire_kernel == '-':
+      sys.stdout.write(text)
+    else:
+      with open(args.hip_wire_kernel, 'w') as f:
         f.write(text)
   if args.hip_backend:
     run(stencil, args)

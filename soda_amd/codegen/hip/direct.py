@@ -206,7 +206,8 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
       lines, tile = _direct_rows_kernel(mod, stage, name + '_v%d' % vec, vec)
       kernel_ids.append(mod.add_kernel(
           KernelDesc(name + '_v%d' % vec, (DIRECT_BLOCK, 1, 1), tile,
-                     note='direct rows V%d' % vec), '\n'.join(lines) + '\n'))
+                     note='direct rows V%d' % vec, tune=dict(vec=vec)),
+          '\n'.join(lines) + '\n'))
       continue
     parents = list(stage.taps)
     lo, hi, keep = _interior(st, stage)

@@ -25,6 +25,95 @@ from soda_amd import core
 from soda_amd.codegen.hip import lower
 
 
+def emit_source(w, var: str, source: str) -> None:
+  """`const char* const <var>[]`: the kernel text, split so that no string
+  literal exceeds compiler limits."""
+  w('const char* const %s[] = {' % var)
+  step = 8000
+  for i in range(0, len(source), step):
+    w('R"SODA_KERNELS(' + source[i:i + step] + ')SODA_KERNELS",')
+  w('nullptr};')
+
+
+def emit_plan(w, func: str, plan) -> None:
+  """`soda_hip_plan_t <func>()` from a ctypes runtime.Plan."""
+  w('soda_hip_plan_t %s() {' % func)
+  w('  soda_hip_plan_t plan;')
+  w('  memset(&plan, 0, sizeof plan);')
+  w('  plan.abi_version = SODA_HIP_ABI_VERSION;')
+  for field in ('dim', 'num_inputs', 'num_outputs', 'num_locals', 'num_params'):
+    w('  plan.%s = %d;' % (field, getattr(plan, field)))
+  for i in range(plan.num_params):
+    w('  plan.param_elems[%d] = %d;' % (i, plan.param_elems[i]))
+  slots = (plan.num_inputs + plan.num_outputs + plan.num_locals +
+           plan.num_params)
+  for i in range(slots):
+    w('  plan.elem_size[%d] = %d;' % (i, plan.elem_size[i]))
+  w('  plan.num_kernels = %d;' % plan.num_kernels)
+  for i in range(plan.num_kernels):
+    d = plan.kernels[i]
+    w('  strcpy(plan.kernels[%d].name, "%s");' % (i, d.name.decode()))
+    for k in range(3):
+      w('  plan.kernels[%d].block[%d] = %d;' % (i, k, d.block[k]))
+    for k in range(4):
+      w('  plan.kernels[%d].tile[%d] = %d;' % (i, k, max(1, d.tile[k])))
+    for field in ('lds_bytes', 'vec', 'march_dim', 'waves_along', 'warm',
+                  'window_extra', 'max_elem', 'vgprs', 'pipe', 'chunk_fixed'):
+      w('  plan.kernels[%d].%s = %d;' % (i, field, getattr(d, field)))
+    for field in ('step_ns', 'warm_saved', 'bytes_per_cell',
+                  'lane_redundancy'):
+      w('  plan.kernels[%d].%s = %rf;' % (i, field, float(getattr(d, field))))
+  w('  plan.num_passes = %d;' % plan.num_passes)
+  for i in range(plan.num_passes):
+    p = plan.passes[i]
+    w('  plan.passes[%d].fused_iters = %d;' % (i, p.fused_iters))
+    w('  plan.passes[%d].num_kernels = %d;' % (i, p.num_kernels))
+    w('  plan.passes[%d].cost = %rf;' % (i, float(p.cost)))
+    for j in range(p.num_kernels):
+      w('  plan.passes[%d].kernel[%d] = %d;' % (i, j, p.kernel[j]))
+  w('  return plan;')
+  w('}')
+
+
+def emit_fail(w, who: str) -> None:
+  w('int Fail(const char* what) {')
+  w('  char text[512];')
+  w('  soda_hip_last_error(text, sizeof text);')
+  w('  fprintf(stderr, "%s: %%s: %%s\\n", what, text);' % who)
+  w('  return 1;')
+  w('}')
+
+
+def emit_program(w, func: str, source_var: str, plan_func: str,
+                 label: str) -> None:
+  """`soda_hip_program_t* <func>()`: JIT + load on first use."""
+  from soda_amd import runtime
+  w('soda_hip_program_t* %s() {' % func)
+  w('  static soda_hip_program_t* program = nullptr;')
+  w('  if (program) return program;')
+  w('  size_t len = 0;')
+  w('  for (const char* const* part = %s; *part; ++part) len += strlen(*part);'
+    % source_var)
+  w('  char* source = new char[len + 1];')
+  w('  source[0] = 0;')
+  w('  for (const char* const* part = %s; *part; ++part) strcat(source, *part);'
+    % source_var)
+  w('  const char* options[] = {%s};' % ', '.join(
+      '"%s"' % o for o in runtime.COMPILE_OPTIONS))
+  w('  void* code = nullptr;')
+  w('  size_t code_size = 0;')
+  w('  int rc = soda_hip_compile(source, "%s", options, %d, &code, '
+    '&code_size);' % (label, len(runtime.COMPILE_OPTIONS)))
+  w('  delete[] source;')
+  w('  if (rc) { Fail("compiling the kernels"); return nullptr; }')
+  w('  const soda_hip_plan_t plan = %s();' % plan_func)
+  w('  rc = soda_hip_program_create(code, code_size, &plan, 0, &program);')
+  w('  soda_hip_free_code(code);')
+  w('  if (rc) { Fail("loading the kernels"); program = nullptr; }')
+  w('  return program;')
+  w('}')
+
+
 def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
                extent=None) -> str:
   """C++ text of the host for `stencil` lowered with `opts` (chunks tuned for
@@ -32,7 +121,11 @@ def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
   from soda_amd import runtime
   opts = runtime.resolve_options(stencil, opts, extent)
   mod = lower.lower(stencil, opts)
-  plan = runtime.make_plan(mod)
+  # register counts of the kernels as this toolchain compiles them: the
+  # library sizes chunk lengths from them at run time
+  res = runtime.kernel_resources(
+      runtime.compile_source(mod.source, '%s.hip' % stencil.app_name))
+  plan = runtime.make_plan(mod, res)
   st = stencil
   dim = st.dim
   app = st.app_name
@@ -48,77 +141,13 @@ def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
   w('#include "soda_hip.h"')
   w('')
   w('namespace {')
-  # the kernel text: split so that no string literal exceeds compiler limits
-  w('const char* const kSodaSource[] = {')
-  src = mod.source
-  step = 8000
-  for i in range(0, len(src), step):
-    chunk = src[i:i + step]
-    w('R"SODA_KERNELS(' + chunk + ')SODA_KERNELS",')
-  w('};')
+  emit_source(w, 'kSodaSource', mod.source)
   w('')
-  w('soda_hip_plan_t MakePlan() {')
-  w('  soda_hip_plan_t plan;')
-  w('  memset(&plan, 0, sizeof plan);')
-  w('  plan.abi_version = SODA_HIP_ABI_VERSION;')
-  w('  plan.dim = %d;' % plan.dim)
-  w('  plan.num_inputs = %d;' % plan.num_inputs)
-  w('  plan.num_outputs = %d;' % plan.num_outputs)
-  w('  plan.num_locals = %d;' % plan.num_locals)
-  w('  plan.num_params = %d;' % plan.num_params)
-  for i in range(plan.num_params):
-    w('  plan.param_elems[%d] = %d;' % (i, plan.param_elems[i]))
-  for i, s in enumerate(mod.elem_size):
-    w('  plan.elem_size[%d] = %d;' % (i, s))
-  w('  plan.num_kernels = %d;' % plan.num_kernels)
-  for i, k in enumerate(mod.kernels):
-    w('  strcpy(plan.kernels[%d].name, "%s");' % (i, k.name))
-    for d in range(3):
-      w('  plan.kernels[%d].block[%d] = %d;' % (i, d, k.block[d]))
-    tile = list(k.tile) + [1] * (4 - len(k.tile))
-    for d in range(4):
-      w('  plan.kernels[%d].tile[%d] = %d;' % (i, d, tile[d]))
-    w('  plan.kernels[%d].lds_bytes = %d;' % (i, k.lds_bytes))
-  w('  plan.num_passes = %d;' % plan.num_passes)
-  for i in range(plan.num_passes):
-    p = plan.passes[i]
-    w('  plan.passes[%d].fused_iters = %d;' % (i, p.fused_iters))
-    w('  plan.passes[%d].num_kernels = %d;' % (i, p.num_kernels))
-    w('  plan.passes[%d].cost = %rf;' % (i, float(p.cost)))
-    for j in range(p.num_kernels):
-      w('  plan.passes[%d].kernel[%d] = %d;' % (i, j, p.kernel[j]))
-  w('  return plan;')
-  w('}')
+  emit_plan(w, 'MakePlan', plan)
   w('')
-  w('int Fail(const char* what) {')
-  w('  char text[512];')
-  w('  soda_hip_last_error(text, sizeof text);')
-  w('  fprintf(stderr, "soda::app::%s: %%s: %%s\\n", what, text);' % app)
-  w('  return 1;')
-  w('}')
+  emit_fail(w, 'soda::app::%s' % app)
   w('')
-  w('soda_hip_program_t* Program() {')
-  w('  static soda_hip_program_t* program = nullptr;')
-  w('  if (program) return program;')
-  w('  size_t len = 0;')
-  w('  for (const char* part : kSodaSource) len += strlen(part);')
-  w('  char* source = new char[len + 1];')
-  w('  source[0] = 0;')
-  w('  for (const char* part : kSodaSource) strcat(source, part);')
-  w('  const char* options[] = {%s};' % ', '.join(
-      '"%s"' % o for o in runtime.COMPILE_OPTIONS))
-  w('  void* code = nullptr;')
-  w('  size_t code_size = 0;')
-  w('  int rc = soda_hip_compile(source, "%s.hip", options, %d, &code, '
-    '&code_size);' % (app, len(runtime.COMPILE_OPTIONS)))
-  w('  delete[] source;')
-  w('  if (rc) { Fail("compiling the kernels"); return nullptr; }')
-  w('  const soda_hip_plan_t plan = MakePlan();')
-  w('  rc = soda_hip_program_create(code, code_size, &plan, 0, &program);')
-  w('  soda_hip_free_code(code);')
-  w('  if (rc) { Fail("loading the kernels"); program = nullptr; }')
-  w('  return program;')
-  w('}')
+  emit_program(w, 'Program', 'kSodaSource', 'MakePlan', '%s.hip' % app)
   w('}  // namespace')
   w('')
   # the operator

@@ -111,7 +111,8 @@ def add_lds2d_pass(mod: Module, tile_rows: int = LDS2D_TILE_ROWS,
   w('}')
   idx = mod.add_kernel(
       KernelDesc(name, (256, 1, 1), (width, tile_rows),
-                 lds_bytes=0, note='lds2d'), '\n'.join(L) + '\n')
+                 lds_bytes=0, note='lds2d', tune=dict(vec=4)),
+      '\n'.join(L) + '\n')
   p = PassDesc(1, [idx], 'lds2d',
                dict(bytes_per_cell_min=table[iname].size_in_bytes +
                     stage.haoda_type.size_in_bytes,

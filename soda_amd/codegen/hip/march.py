@@ -1137,6 +1137,24 @@ class _MarchKernel:
           'too far along dim 0 for %d cells per lane' %
           (self.shift_temps, MAX_SHIFT_TEMPS, self.V))
     self.est_regs += self.shift_temps
+    # launch-time model (include/soda_hip.h, soda_hip_kernel_desc_t): vector
+    # instructions one row step of the busiest wave issues, and the part of
+    # the warm-up the peeled steps skip, in row steps
+    stages = [n for n in self.nodes if n.stage is not None]
+    per_wave = []
+    for wv in range(self.W):
+      ops = 0.0
+      for n in stages:
+        if n.owner != wv:
+          continue
+        cost = sum(ir.op_count(l.expr) for l in n.stage.stmt.let) + \
+            ir.op_count(n.stage.stmt.expr) + 0.5
+        wide = 2.0 if n.ctype in ('double', 'int64_t', 'uint64_t') else 1.0
+        ops += cost * wide * self.V * len(self.rows_of(n))
+      per_wave.append(ops + 8.0)
+    step_ops = max(per_wave)
+    saved = sum(1 for i in range(self.peeled) for n in stages
+                if not self.stage_needed(n, i)) / float(max(1, len(stages)))
     if self.dim == 2:
       tile = (self.strip_cells * self.wx, self.cfg.chunk_rows * self.cfg.waves_y)
     else:
@@ -1153,7 +1171,10 @@ class _MarchKernel:
                    tune=dict(axis=self.ax, waves_along=self.cfg.waves_y if self.dim == 2 else 1,
                              waves_per_block=self.waves, warm=self.warm,
                              fixed=self.cfg.chunk_fixed, occupancy=self.cfg.occupancy,
-                             pipe=self.W, peel_trips=self.peeled // self.U,
+                             pipe=self.W, vec=self.V, step_ops=step_ops,
+                             warm_saved=saved,
+                             lane_redundancy=64.0 / self.strip_lanes,
+                             peel_trips=self.peeled // self.U,
                              peel_trips_max=self.peel_trips_max,
                              fused=self.T,
                              window_extra=(self.m_hi - self.m_lo) if self.buf else None,

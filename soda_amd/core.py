@@ -282,6 +282,72 @@ class Stencil:
       return name
     raise util.InternalError('unknown name: %s' % name)
 
+  def produce_offsets(self) -> Dict[str, int]:
+    """Stream position at which every INPUT tensor is produced relative to
+    the earliest one -- the delay the reference host applies when it lays the
+    inputs out (`produce_offset`, ref frt/host.py:241-246).
+
+    Restates the integer program of ref core.py:371-426 over the tensors of
+    all iterations: variables p_T (produced) and c_T (kept until), minimise
+    sum(c_T - p_T) subject to c_T >= p_T and, for every load of L by a
+    statement S stored at linear offset s with linear load offsets o:
+        p_L <= p_S + (s - max o)      (the newest element exists)
+        c_L >= p_S + (s - min o)      (the oldest one has not been dropped)
+    with p of input 0 pinned at 0; the result is shifted so the earliest
+    input sits at 0 (core.py:416-421).  Linear offsets are `serialize`d with
+    the program's tile size (ref tensor.py:71-92).  Solved with SciPy's HiGHS
+    (the reference uses PuLP/CBC: where the optimum is not unique the two may
+    pick different offsets -- one-input programs have nothing to solve)."""
+    if len(self.input_names) == 1:
+      return {self.input_names[0]: 0}
+    import numpy as np
+    from scipy import optimize
+    tile = self.tile_size
+    names = list(self.tensor_names)
+    index = {n: i for i, n in enumerate(names)}
+    nt = len(names)
+    # variables: p_0..p_{nt-1}, c_0..c_{nt-1}
+    rows, lo, hi = [], [], []
+
+    def constraint(coeffs, lower, upper):
+      row = np.zeros(2 * nt)
+      for j, v in coeffs:
+        row[j] += v
+      rows.append(row)
+      lo.append(lower)
+      hi.append(upper)
+
+    for i in range(nt):
+      constraint([(nt + i, 1.0), (i, -1.0)], 0.0, np.inf)       # c >= p
+    for it in range(self.iterate):
+      for stage in self.ordered_stages:
+        s_name = self.name_in_iter(stage.name, it)
+        s_off = util.serialize(stage.st_idx, tile)
+        for parent, refs in stage.loads.items():
+          if parent in self.param_names:
+            continue
+          l_name = self.name_in_iter(parent, it)
+          offs = [util.serialize(r.idx, tile) for r in refs]
+          ps, pl, cl = index[s_name], index[l_name], nt + index[l_name]
+          # p_L - p_S <= s - newest
+          constraint([(pl, 1.0), (ps, -1.0)], -np.inf, s_off - max(offs))
+          # c_L - p_S >= s - oldest
+          constraint([(cl, 1.0), (ps, -1.0)], s_off - min(offs), np.inf)
+    cost = np.concatenate([-np.ones(nt), np.ones(nt)])
+    bounds_lo = np.full(2 * nt, -np.inf)
+    bounds_hi = np.full(2 * nt, np.inf)
+    bounds_lo[index[self.input_names[0]]] = 0.0
+    bounds_hi[index[self.input_names[0]]] = 0.0
+    res = optimize.milp(
+        cost, constraints=optimize.LinearConstraint(np.array(rows), lo, hi),
+        integrality=np.ones(2 * nt),
+        bounds=optimize.Bounds(bounds_lo, bounds_hi))
+    if not res.success:
+      raise util.InternalError('unexpected ILP status: %s' % res.message)
+    p = {n: int(round(res.x[index[n]])) for n in self.input_names}
+    base = min(p.values())
+    return {n: v - base for n, v in p.items()}
+
   @property
   def tensor_names(self) -> Tuple[str, ...]:
     """Every tensor of the unrolled program in chronological order."""

@@ -17,7 +17,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -79,6 +81,8 @@ struct soda_hip_program {
   int32_t last_launches = 0;
   int32_t last_fused = 0;
   void* debug = nullptr;              // time-stamp buffer of diagnostic builds
+  // measured time of one launch of every pass, per extent (calibrate)
+  std::map<std::array<int32_t, SODA_HIP_MAX_DIM>, std::vector<double>> measured;
 };
 
 struct soda_hip_event {
@@ -183,6 +187,22 @@ int soda_hip_compile(const char* source, const char* name,
 
 void soda_hip_free_code(void* code) { free(code); }
 
+static int check_plan(const soda_hip_plan_t* p);
+static int plan_geometry_c(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t* tiles, float* pass_ns);
+static int plan_schedule_c(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t iterate, int32_t* count);
+
+int soda_hip_plan_geometry(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t* tiles, float* pass_ns) {
+  return plan_geometry_c(plan, extent, tiles, pass_ns);
+}
+
+int soda_hip_plan_schedule(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t iterate, int32_t* count) {
+  return plan_schedule_c(plan, extent, iterate, count);
+}
+
 static int check_plan(const soda_hip_plan_t* p) {
   if (p->abi_version != SODA_HIP_ABI_VERSION)
     return fail(SODA_HIP_ERR_INVALID, "plan: ABI version mismatch");
@@ -218,6 +238,10 @@ static int check_plan(const soda_hip_plan_t* p) {
       if (d.tile[i] < 1) return fail(SODA_HIP_ERR_INVALID, "plan: bad tile");
     if (d.lds_bytes < 0 || d.lds_bytes > 160 * 1024)
       return fail(SODA_HIP_ERR_INVALID, "plan: bad lds_bytes");
+    if (d.vec < 0 || d.march_dim < 0 || d.march_dim > p->dim ||
+        d.waves_along < 0 || d.warm < 0 || d.vgprs < 0 || d.pipe < 0 ||
+        d.step_ns < 0 || d.bytes_per_cell < 0 || d.warm_saved < 0)
+      return fail(SODA_HIP_ERR_INVALID, "plan: bad launch-geometry field");
   }
   int prev = 1 << 30;
   for (int i = 0; i < p->num_passes; ++i) {
@@ -293,13 +317,191 @@ int soda_hip_program_destroy(soda_hip_program_t* p) {
   return SODA_HIP_OK;
 }
 
+// ---- launch geometry --------------------------------------------------------
+// MI355X: 256 CUs x 4 SIMDs; 512 VGPRs per lane per SIMD in granules of 8
+// (MI355X_MICROARCH.md, Register files); sustained HBM rate of a streaming
+// kernel of this family ~6.3 TB/s (profiles/).
+namespace {
+
+const int kSimds = 1024;
+const double kHbmBytesPerNs = 6300.0;
+const double kLaunchNs = 2000.0;
+const int64_t kBufWindowMax = 1ll << 30;      // SODA_BUF_WINDOW_MAX, soda_rt.h
+
+int waves_per_simd(int vgprs) {
+  int alloc = vgprs < 8 ? 8 : (vgprs + 7) / 8 * 8;
+  int w = 512 / alloc;
+  return w < 1 ? 1 : w > 8 ? 8 : w;
+}
+
+struct Geometry {
+  int32_t tile[SODA_HIP_MAX_DIM];
+  double ns;          // modelled time of one launch; 0: no model
+};
+
+// Length (cells along the marched dimension) one wave should own.  The waves
+// of a launch are dealt evenly over the SIMDs, a SIMD's waves share its issue
+// slots, and every wave pays `warm` pipeline warm-up steps on top of its
+// chunk, so  time ~ k * eff(k) * (chunk + warm),  k = waves per SIMD.  One
+// wave alone on a SIMD issues at half rate, two still leave bubbles; a kernel
+// that fuses few iterations is latency-bound and wants >= 4 waves per SIMD.
+// A register-limited grid that fills the last 2-3 % of its wave slots runs
+// slower than one a row longer that leaves them free (measured).
+int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
+                    const int32_t* extent, int dim, int64_t others) {
+  const int axis = d.march_dim - 1;
+  const int32_t n = extent[axis];
+  const int wpb = (d.block[0] * d.block[1] * d.block[2] + 63) / 64;
+  const int along = d.waves_along > 0 ? d.waves_along : 1;
+  const double warm = d.warm - d.warm_saved;
+  (void)tile; (void)dim;
+  const int cap = waves_per_simd(d.vgprs);
+  if (d.pipe > 1) {
+    // stage-pipelined blocks: the warm-up is paid once per block; ~3.5x the
+    // warm-up is best on every grid -- but never a grid that needs a second,
+    // nearly empty round of blocks (a block holds one wave slot on `pipe`
+    // SIMDs; measured: 2592 blocks on 1792 slots cost 15 %)
+    int32_t target = (int32_t)(3.5 * d.warm) > 64 ? (int32_t)(3.5 * d.warm) : 64;
+    int64_t chunks = (n + target - 1) / target;
+    if (chunks < 1) chunks = 1;
+    const int64_t slots = (int64_t)kSimds * cap / d.pipe;
+    int64_t blocks = others * chunks;
+    if (blocks > slots * 0.975 && blocks < slots * 1.6) {
+      chunks = (int64_t)(slots * 0.975) / others;
+      if (chunks < 1) chunks = 1;
+    }
+    return (int32_t)((n + chunks - 1) / chunks);
+  }
+  const int k_min = d.warm <= 12 ? 4 : 2;
+  double best_cost = 0;
+  int32_t best = 0;
+  for (int32_t chunk = n < 8 ? n : 8; chunk <= n; ++chunk) {
+    int64_t chunks = (n + chunk - 1) / chunk;
+    int64_t blocks = others * ((chunks + along - 1) / along);
+    int64_t waves = blocks * wpb;
+    int64_t k = (waves + kSimds - 1) / kSimds;
+    if (k >= cap && waves > 0.975 * k * kSimds) ++k;
+    if (k < k_min) k = k_min;
+    double cost = k * (k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0) * (chunk + warm);
+    if (!best || cost < best_cost || (cost == best_cost && chunk > best)) {
+      best_cost = cost;
+      best = chunk;
+    }
+  }
+  if (d.warm <= 12 && best > 64) best = 64;   // latency-bound: more, shorter waves
+  int64_t chunks = (n + best - 1) / best;
+  return (int32_t)((n + chunks - 1) / chunks);   // same count, equal lengths
+}
+
+int kernel_geometry(const soda_hip_kernel_desc_t& d, const int32_t* extent,
+                    int dim, Geometry* g) {
+  char buf[384];
+  int64_t cells = 1;
+  for (int i = 0; i < SODA_HIP_MAX_DIM; ++i) {
+    g->tile[i] = i < dim ? d.tile[i] : 1;
+    if (i < dim) cells *= extent[i];
+  }
+  g->ns = 0;
+  if (d.vec > 1 && extent[0] % d.vec) {
+    snprintf(buf, sizeof buf,
+             "%s was built for rows that are a multiple of %d cells; extent[0] "
+             "= %d is not (rebuild the program for this extent)", d.name, d.vec,
+             extent[0]);
+    return fail(SODA_HIP_ERR_INVALID, buf);
+  }
+  double rows_factor = 1.0;
+  double valu_ns = 0;
+  if (d.march_dim > 0) {
+    if (d.march_dim > dim)
+      return fail(SODA_HIP_ERR_INVALID, "plan: bad march_dim");
+    const int axis = d.march_dim - 1;
+    const int along = d.waves_along > 0 ? d.waves_along : 1;
+    const int wpb = (d.block[0] * d.block[1] * d.block[2] + 63) / 64;
+    int64_t others = 1;
+    for (int i = 0; i < dim; ++i)
+      if (i != axis) others *= (extent[i] + g->tile[i] - 1) / g->tile[i];
+    int32_t per_wave = g->tile[axis] / along;
+    if (per_wave < 1) per_wave = 1;
+    if (!d.chunk_fixed && d.vgprs > 0)
+      per_wave = tuned_chunk(d, g->tile, extent, dim, others);
+    if (d.window_extra >= 0) {
+      int64_t plane = d.max_elem > 0 ? d.max_elem : 8;
+      for (int i = 0; i < axis; ++i) plane *= extent[i];
+      int64_t limit = kBufWindowMax / plane - d.window_extra;
+      if (limit < 1) {
+        snprintf(buf, sizeof buf,
+                 "%s: one plane of this extent (%lld bytes) exceeds the 1 GiB "
+                 "buffer window of the marching kernels; use the `direct` "
+                 "strategy", d.name, (long long)plane);
+        return fail(SODA_HIP_ERR_INVALID, buf);
+      }
+      if (per_wave > limit) {
+        if (d.chunk_fixed) {
+          snprintf(buf, sizeof buf,
+                   "%s: chunks of %d planes exceed the 1 GiB buffer window on "
+                   "this extent (at most %lld)", d.name, per_wave,
+                   (long long)limit);
+          return fail(SODA_HIP_ERR_INVALID, buf);
+        }
+        per_wave = (int32_t)limit;
+      }
+    }
+    g->tile[axis] = per_wave * along;
+    const int32_t n = extent[axis];
+    const int64_t chunks = (n + per_wave - 1) / per_wave;
+    const int64_t waves = others * ((chunks + along - 1) / along) * wpb;
+    const int pipe = d.pipe > 0 ? d.pipe : 1;
+    int64_t k = (waves + kSimds - 1) / kSimds;
+    if (k < 1) k = 1;
+    const double eff = k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0;
+    double steps = per_wave + d.warm - d.warm_saved;
+    if (steps < 1) steps = 1;
+    valu_ns = k * eff * steps * d.step_ns / pipe;
+    rows_factor = (per_wave + (double)d.warm) / per_wave;
+  }
+  if (d.step_ns > 0 || d.bytes_per_cell > 0) {
+    const double lanes = d.lane_redundancy > 1 ? d.lane_redundancy : 1.0;
+    // reads are re-fetched for halo lanes and warm-up rows, writes are not
+    const double bytes = cells * (double)d.bytes_per_cell *
+                         (0.5 * lanes * rows_factor + 0.5);
+    const double mem_ns = bytes / kHbmBytesPerNs;
+    const double hi = valu_ns > mem_ns ? valu_ns : mem_ns;
+    const double lo = valu_ns > mem_ns ? mem_ns : valu_ns;
+    g->ns = hi + 0.15 * lo + kLaunchNs;
+  }
+  return SODA_HIP_OK;
+}
+
+// tiles of every kernel and time of every pass for `extent`
+int plan_geometry(const soda_hip_plan_t& plan, const int32_t* extent,
+                  std::vector<Geometry>* geo, std::vector<double>* pass_ns) {
+  geo->resize(plan.num_kernels);
+  for (int k = 0; k < plan.num_kernels; ++k)
+    if (int rc = kernel_geometry(plan.kernels[k], extent, plan.dim, &(*geo)[k]))
+      return rc;
+  pass_ns->assign(plan.num_passes, 0.0);
+  for (int i = 0; i < plan.num_passes; ++i) {
+    double t = 0;
+    bool modelled = true;
+    for (int j = 0; j < plan.passes[i].num_kernels; ++j) {
+      const Geometry& g = (*geo)[plan.passes[i].kernel[j]];
+      if (g.ns <= 0) modelled = false;
+      t += g.ns;
+    }
+    (*pass_ns)[i] = modelled ? t : 0.0;
+  }
+  return SODA_HIP_OK;
+}
+
+}  // namespace
+
 static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
-                  hipStream_t stream) {
+                  const int32_t* tile, hipStream_t stream) {
   const soda_hip_kernel_desc_t& d = p->plan.kernels[k];
   soda_hip_kargs_t args = base;
   int64_t blocks = 1;
   for (int i = 0; i < SODA_HIP_MAX_DIM; ++i) {
-    int32_t t = i < p->plan.dim ? d.tile[i] : 1;
+    int32_t t = i < p->plan.dim ? tile[i] : 1;
     args.tile[i] = t;
     args.ntile[i] = (args.extent[i] + t - 1) / t;
     blocks *= args.ntile[i];
@@ -315,11 +517,20 @@ static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
   return SODA_HIP_OK;
 }
 
-static int schedule(const soda_hip_plan_t& plan, int32_t iterate,
+static int schedule(const soda_hip_plan_t& plan,
+                    const std::vector<double>& pass_ns, int32_t iterate,
                     int32_t* count, int32_t* total) {
-  bool costed = false;
+  // modelled times for this extent where every pass has one, else the plan's
+  // static relative costs, else greedy
+  std::vector<double> cost(plan.num_passes, 0.0);
+  bool modelled = true;
   for (int i = 0; i < plan.num_passes; ++i)
-    costed = costed || plan.passes[i].cost > 0.f;
+    modelled = modelled && pass_ns[i] > 0;
+  bool costed = modelled;
+  for (int i = 0; i < plan.num_passes; ++i) {
+    cost[i] = modelled ? pass_ns[i] : plan.passes[i].cost;
+    costed = costed || cost[i] > 0;
+  }
   *total = 0;
   if (!costed || iterate > (1 << 20)) {      // greedy, deepest first
     int32_t remaining = iterate;
@@ -339,7 +550,7 @@ static int schedule(const soda_hip_plan_t& plan, int32_t iterate,
   for (int32_t n = 1; n <= iterate; ++n)
     for (int i = 0; i < plan.num_passes; ++i) {
       const int32_t t = plan.passes[i].fused_iters;
-      const double c = plan.passes[i].cost > 0.f ? plan.passes[i].cost : 1e6;
+      const double c = cost[i] > 0 ? cost[i] : 1e12;
       if (t <= n && best[n - t] < 1e299 && best[n - t] + c < best[n]) {
         best[n] = best[n - t] + c;
         pick[n] = (int8_t)i;
@@ -355,6 +566,45 @@ static int schedule(const soda_hip_plan_t& plan, int32_t iterate,
   return SODA_HIP_OK;
 }
 
+static int plan_geometry_c(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t* tiles, float* pass_ns) {
+  if (!plan || !extent) return fail(SODA_HIP_ERR_INVALID, "geometry: NULL argument");
+  if (int rc = check_plan(plan)) return rc;
+  int32_t ext[SODA_HIP_MAX_DIM];
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+    ext[d] = d < plan->dim ? extent[d] : 1;
+    if (ext[d] < 1) return fail(SODA_HIP_ERR_INVALID, "geometry: extent < 1");
+  }
+  std::vector<Geometry> geo;
+  std::vector<double> ns;
+  if (int rc = plan_geometry(*plan, ext, &geo, &ns)) return rc;
+  if (tiles)
+    for (int k = 0; k < plan->num_kernels; ++k)
+      for (int d = 0; d < SODA_HIP_MAX_DIM; ++d)
+        tiles[k * SODA_HIP_MAX_DIM + d] = geo[k].tile[d];
+  if (pass_ns)
+    for (int i = 0; i < plan->num_passes; ++i) pass_ns[i] = (float)ns[i];
+  return SODA_HIP_OK;
+}
+
+static int plan_schedule_c(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t iterate, int32_t* count) {
+  if (!plan || !extent || !count)
+    return fail(SODA_HIP_ERR_INVALID, "schedule: NULL argument");
+  if (iterate < 1) return fail(SODA_HIP_ERR_INVALID, "cannot iterate < 1 times");
+  if (int rc = check_plan(plan)) return rc;
+  int32_t ext[SODA_HIP_MAX_DIM];
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+    ext[d] = d < plan->dim ? extent[d] : 1;
+    if (ext[d] < 1) return fail(SODA_HIP_ERR_INVALID, "schedule: extent < 1");
+  }
+  std::vector<Geometry> geo;
+  std::vector<double> ns;
+  if (int rc = plan_geometry(*plan, ext, &geo, &ns)) return rc;
+  int32_t total = 0;
+  return schedule(*plan, ns, iterate, count, &total);
+}
+
 int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,
                         int32_t iterate, void* stream_) {
@@ -362,11 +612,25 @@ int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
                                     nullptr, iterate, stream_);
 }
 
+static int run_core(soda_hip_program_t* p, void* const* outputs,
+                    const void* const* inputs, const int32_t* extent,
+                    const int32_t* origin, const int32_t* global_extent,
+                    int32_t iterate, void* stream_, int force_pass);
+
 int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
                                const void* const* inputs,
                                const int32_t* extent, const int32_t* origin,
                                const int32_t* global_extent, int32_t iterate,
                                void* stream_) {
+  return run_core(p, outputs, inputs, extent, origin, global_extent, iterate,
+                  stream_, -1);
+}
+
+// force_pass >= 0: use only that pass (calibration)
+static int run_core(soda_hip_program_t* p, void* const* outputs,
+                    const void* const* inputs, const int32_t* extent,
+                    const int32_t* origin, const int32_t* global_extent,
+                    int32_t iterate, void* stream_, int force_pass) {
   if (!p || !outputs || !inputs || !extent)
     return fail(SODA_HIP_ERR_INVALID, "run_device: NULL argument");
   const soda_hip_plan_t& plan = p->plan;
@@ -408,16 +672,40 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
   // cost (100 iterations with passes of 12 / 8 / 4 / 1: 7 x 12 + 2 x 8 beats
   // 8 x 12 + 4); without costs, as many of the deepest kind as fit, then the
   // next...
+  std::vector<Geometry> geo;
+  std::vector<double> pass_ns;
+  if (int rc = plan_geometry(plan, base.extent, &geo, &pass_ns)) return rc;
   int32_t count[SODA_HIP_MAX_PASSES];
   int32_t total = 0;
-  if (int rc = schedule(plan, iterate, count, &total)) return rc;
+  if (force_pass >= 0) {
+    if (force_pass >= plan.num_passes ||
+        iterate % plan.passes[force_pass].fused_iters)
+      return fail(SODA_HIP_ERR_INVALID, "run_core: bad forced pass");
+    for (int i = 0; i < plan.num_passes; ++i) count[i] = 0;
+    count[force_pass] = total = iterate / plan.passes[force_pass].fused_iters;
+  } else {
+    // measured launch times of this very extent (soda_hip_program_calibrate)
+    // outrank the model
+    std::array<int32_t, SODA_HIP_MAX_DIM> key;
+    for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = base.extent[d];
+    auto it = p->measured.find(key);
+    if (it != p->measured.end()) pass_ns = it->second;
+    if (int rc = schedule(plan, pass_ns, iterate, count, &total)) return rc;
+  }
 
   if (p->debug) base.buf[SODA_HIP_MAX_TENSORS - 1] = p->debug;
   const int in0 = 0, out0 = plan.num_inputs, loc0 = out0 + plan.num_outputs;
   const int prm0 = loc0 + plan.num_locals;
   for (int k = 0; k < plan.num_params; ++k)   // the same in every iteration
     base.buf[prm0 + k] = const_cast<void*>(inputs[plan.num_inputs + k]);
-  for (int l = 0; l < plan.num_locals; ++l) {
+  // scratch for the local tensors -- only if a scheduled pass keeps them in
+  // memory (marching kernels hold them in registers)
+  bool need_locals = false;
+  for (int i = 0; i < plan.num_passes; ++i)
+    for (int k = 0; count[i] && k < plan.passes[i].num_kernels; ++k)
+      need_locals = need_locals ||
+                    plan.kernels[plan.passes[i].kernel[k]].march_dim == 0;
+  for (int l = 0; need_locals && l < plan.num_locals; ++l) {
     int rc = ensure(p->locals[l], (size_t)cells * plan.elem_size[loc0 + l]);
     if (rc) return rc;
     base.buf[loc0 + l] = p->locals[l].ptr;
@@ -442,7 +730,8 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
       for (int o = 0; o < plan.num_outputs; ++o)
         base.buf[out0 + o] = to_out ? outputs[o] : p->temps[o].ptr;
       for (int k = 0; k < plan.passes[i].num_kernels; ++k) {
-        int rc = launch(p, plan.passes[i].kernel[k], base, stream);
+        const int kk = plan.passes[i].kernel[k];
+        int rc = launch(p, kk, base, geo[kk].tile, stream);
         if (rc) return rc;
         ++p->last_launches;
         if (i == 0) ++p->last_fused;
@@ -452,6 +741,110 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
     }
   }
   return SODA_HIP_OK;
+}
+
+int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
+                               int32_t launches, void* stream_) {
+  if (!p || !extent) return fail(SODA_HIP_ERR_INVALID, "calibrate: NULL argument");
+  const soda_hip_plan_t& plan = p->plan;
+  if (launches < 2) launches = 4;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipSetDevice(p->device));
+  std::array<int32_t, SODA_HIP_MAX_DIM> key;
+  int64_t cells = 1;
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+    key[d] = d < plan.dim ? extent[d] : 1;
+    if (key[d] < 1) return fail(SODA_HIP_ERR_INVALID, "calibrate: extent < 1");
+    cells *= key[d];
+  }
+  if (plan.num_passes < 2 || plan.num_inputs != plan.num_outputs) {
+    p->measured.erase(key);          // nothing to choose between
+    return SODA_HIP_OK;
+  }
+  // stand-in arrays: inputs (a byte pattern that reads as ~0.75 in fp32, small
+  // positive integers otherwise), outputs, params
+  std::vector<DeviceBuffer> bufs(plan.num_inputs + plan.num_outputs +
+                                 plan.num_params);
+  std::vector<const void*> ins;
+  std::vector<void*> outs;
+  int rc = SODA_HIP_OK;
+  const int prm0 = plan.num_inputs + plan.num_outputs + plan.num_locals;
+  for (size_t b = 0; b < bufs.size() && rc == SODA_HIP_OK; ++b) {
+    size_t bytes;
+    if ((int)b < plan.num_inputs + plan.num_outputs)
+      bytes = (size_t)cells * plan.elem_size[b];
+    else
+      bytes = (size_t)plan.param_elems[b - plan.num_inputs - plan.num_outputs] *
+              plan.elem_size[prm0 + (b - plan.num_inputs - plan.num_outputs)];
+    rc = ensure(bufs[b], bytes);
+    if (rc == SODA_HIP_OK &&
+        hipMemsetAsync(bufs[b].ptr, 0x3f, bytes, stream) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipMemsetAsync");
+  }
+  std::vector<double> ns(plan.num_passes, 0.0);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (rc == SODA_HIP_OK && (hipEventCreate(&e0) != hipSuccess ||
+                            hipEventCreate(&e1) != hipSuccess))
+    rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventCreate");
+  if (rc == SODA_HIP_OK) {
+    for (int i = 0; i < plan.num_inputs; ++i) ins.push_back(bufs[i].ptr);
+    for (int k = 0; k < plan.num_params; ++k)
+      ins.push_back(bufs[plan.num_inputs + plan.num_outputs + k].ptr);
+    for (int o = 0; o < plan.num_outputs; ++o)
+      outs.push_back(bufs[plan.num_inputs + o].ptr);
+    // four rounds over all passes; the first two bring the clocks to where a
+    // long run holds them (a launch a millisecond after idle reads 20-30 %
+    // slow, and not equally for every pass), the faster of the last two counts
+    for (int round = 0; round < 4 && rc == SODA_HIP_OK; ++round)
+      for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
+        const int32_t iters = plan.passes[i].fused_iters * launches;
+        (void)hipEventRecord(e0, stream);
+        rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
+                      iters, stream_, i);
+        (void)hipEventRecord(e1, stream);
+        if (rc == SODA_HIP_OK && hipEventSynchronize(e1) != hipSuccess)
+          rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventSynchronize");
+        float ms = 0;
+        if (rc == SODA_HIP_OK) (void)hipEventElapsedTime(&ms, e0, e1);
+        const double t = ms * 1e6 / launches;
+        if (round == 2 || (round == 3 && t < ns[i])) ns[i] = t;
+      }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (auto& b : bufs)
+    if (b.ptr) (void)hipFree(b.ptr);
+  if (rc == SODA_HIP_OK) p->measured[key] = ns;
+  return rc;
+}
+
+int soda_hip_program_pass_times(soda_hip_program_t* p, const int32_t* extent,
+                                float* pass_ns, int32_t* measured) {
+  if (!p || !extent || !pass_ns)
+    return fail(SODA_HIP_ERR_INVALID, "pass_times: NULL argument");
+  const soda_hip_plan_t& plan = p->plan;
+  std::array<int32_t, SODA_HIP_MAX_DIM> key;
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = d < plan.dim ? extent[d] : 1;
+  auto it = p->measured.find(key);
+  if (measured) *measured = it != p->measured.end();
+  if (it != p->measured.end()) {
+    for (int i = 0; i < plan.num_passes; ++i) pass_ns[i] = (float)it->second[i];
+    return SODA_HIP_OK;
+  }
+  return plan_geometry_c(&plan, key.data(), nullptr, pass_ns);
+}
+
+int soda_hip_program_schedule(soda_hip_program_t* p, const int32_t* extent,
+                              int32_t iterate, int32_t* count) {
+  if (!p || !extent || !count)
+    return fail(SODA_HIP_ERR_INVALID, "program_schedule: NULL argument");
+  if (iterate < 1) return fail(SODA_HIP_ERR_INVALID, "cannot iterate < 1 times");
+  std::vector<float> ns(p->plan.num_passes);
+  if (int rc = soda_hip_program_pass_times(p, extent, ns.data(), nullptr))
+    return rc;
+  std::vector<double> t(ns.begin(), ns.end());
+  int32_t total = 0;
+  return schedule(p->plan, t, iterate, count, &total);
 }
 
 int soda_hip_program_set_debug_buffer(soda_hip_program_t* p, void* buf) {
@@ -613,6 +1006,211 @@ int soda_hip_run_host(soda_hip_program_t* p,
                       const soda_hip_host_tensor_t* inputs,
                       const soda_hip_host_tensor_t* outputs, int32_t iterate) {
   return soda_hip_run_host_box(p, inputs, outputs, iterate, nullptr, nullptr);
+}
+
+// -- wire format: <app>_kernel on banked streams -------------------------------
+
+struct soda_hip_stream {
+  soda_hip_stream_desc_t desc;
+  soda_hip_program* dense = nullptr;
+  std::vector<soda_hip_program*> linear, unwire, wire;
+  std::vector<DeviceBuffer> dense_in, dense_out;   // de-interleaved streams
+  std::vector<DeviceBuffer> host_banks;            // run_host staging
+  bool dense_failed = false;
+  int last_mode = 0;
+};
+
+int soda_hip_stream_create(const soda_hip_stream_desc_t* desc,
+                           soda_hip_program_t* dense,
+                           soda_hip_program_t* const* linear,
+                           soda_hip_program_t* const* unwire,
+                           soda_hip_program_t* const* wire,
+                           soda_hip_stream_t** stream) {
+  if (!desc || !linear || !wire || !stream)
+    return fail(SODA_HIP_ERR_INVALID, "stream_create: NULL argument");
+  *stream = nullptr;
+  const int nt = desc->num_inputs + desc->num_outputs;
+  if (desc->dim < 1 || desc->dim > SODA_HIP_MAX_DIM || desc->num_inputs < 1 ||
+      desc->num_outputs < 1 || nt > SODA_HIP_MAX_TENSORS || desc->iterate < 1 ||
+      desc->num_linear < 1 || desc->num_linear > 4 ||
+      desc->linear_vec[desc->num_linear - 1] != 1)
+    return fail(SODA_HIP_ERR_INVALID, "stream_create: bad description");
+  for (int t = 0; t < nt; ++t)
+    if (desc->banks[t] < 1 || desc->elem_size[t] < 1 ||
+        desc->elems_per_cycle[t] < 1 || desc->shift[t] < 0)
+      return fail(SODA_HIP_ERR_INVALID, "stream_create: bad tensor entry");
+  for (int t = 1; t < nt; ++t)
+    if (desc->elems_per_cycle[t] != desc->elems_per_cycle[0])
+      return fail(SODA_HIP_ERR_UNSUPPORTED,
+                  "stream mode needs every tensor to move the same number of "
+                  "elements per cycle (burst width / element width x banks)");
+  for (int i = 0; i < desc->num_inputs; ++i)
+    if ((desc->banks[i] > 1 || desc->shift[i]) && (!unwire || !unwire[i]))
+      return fail(SODA_HIP_ERR_INVALID, "stream_create: missing unwire kernel");
+  for (int k = 0; k < desc->num_linear; ++k)
+    if (!linear[k]) return fail(SODA_HIP_ERR_INVALID, "stream_create: NULL linear");
+  for (int o = 0; o < desc->num_outputs; ++o)
+    if (!wire[o]) return fail(SODA_HIP_ERR_INVALID, "stream_create: NULL wire");
+  soda_hip_stream* s = new (std::nothrow) soda_hip_stream;
+  if (!s) return fail(SODA_HIP_ERR_NOMEM, "new stream");
+  s->desc = *desc;
+  s->dense = dense;
+  s->dense_failed = dense == nullptr;
+  s->linear.assign(linear, linear + desc->num_linear);
+  s->unwire.resize(desc->num_inputs, nullptr);
+  for (int i = 0; unwire && i < desc->num_inputs; ++i) s->unwire[i] = unwire[i];
+  s->wire.assign(wire, wire + desc->num_outputs);
+  s->dense_in.resize(desc->num_inputs);
+  s->dense_out.resize(desc->num_outputs);
+  *stream = s;
+  return SODA_HIP_OK;
+}
+
+int soda_hip_stream_destroy(soda_hip_stream_t* s) {
+  if (!s) return SODA_HIP_OK;
+  for (auto* v : {&s->dense_in, &s->dense_out, &s->host_banks})
+    for (auto& b : *v)
+      if (b.ptr) (void)hipFree(b.ptr);
+  delete s;
+  return SODA_HIP_OK;
+}
+
+int soda_hip_stream_last_mode(soda_hip_stream_t* s) { return s ? s->last_mode : 0; }
+
+int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
+                               const void* const* in_banks,
+                               uint64_t coalesced_data_num, void* hip_stream) {
+  if (!s || !out_banks || !in_banks)
+    return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL argument");
+  const soda_hip_stream_desc_t& d = s->desc;
+  const uint64_t n64 = coalesced_data_num * (uint64_t)d.elems_per_cycle[0];
+  if (n64 < 1 || n64 >= (1ull << 31))
+    return fail(SODA_HIP_ERR_INVALID, "stream_run: stream length out of range");
+  const int32_t n = (int32_t)n64;
+  const int32_t ext1[1] = {n};
+  HIP_TRY(hipSetDevice(s->linear.back()->device));
+  // 1. un-interleave (and un-delay) the inputs
+  std::vector<const void*> din(d.num_inputs);
+  int bank0 = 0;
+  for (int i = 0; i < d.num_inputs; ++i) {
+    const int nb = d.banks[i];
+    for (int b = 0; b < nb; ++b)
+      if (!in_banks[bank0 + b])
+        return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL input bank");
+    if (nb == 1 && d.shift[i] == 0) {
+      din[i] = in_banks[bank0];     // the bank IS the dense stream
+    } else {
+      if (int rc = ensure(s->dense_in[i], (size_t)n * d.elem_size[i])) return rc;
+      void* outs[1] = {s->dense_in[i].ptr};
+      if (int rc = soda_hip_run_device(s->unwire[i], outs, in_banks + bank0, ext1,
+                                       1, hip_stream))
+        return rc;
+      din[i] = s->dense_in[i].ptr;
+    }
+    bank0 += nb;
+  }
+  std::vector<void*> dout(d.num_outputs);
+  for (int o = 0; o < d.num_outputs; ++o) {
+    if (int rc = ensure(s->dense_out[o],
+                        (size_t)n * d.elem_size[d.num_inputs + o]))
+      return rc;
+    dout[o] = s->dense_out[o].ptr;
+  }
+  // 2. the program.  Dense view: the stream is an array of extent (tile...,
+  // rows) iff every tile starts on a row-block boundary -- a tile occupies
+  // round_up(block * extent_last, epc) elements (frt/host.py:137-142), so for
+  // any extent iff block % epc == 0 -- and the void tail (kStencilDistance
+  // elements, :151-162) covers the partial last row the view drops.
+  bool done = false;
+  if (!s->dense_failed && d.dim >= 2) {
+    int64_t block = 1;
+    for (int t = 0; t < d.dim - 1; ++t) block *= d.tile[t];
+    const int64_t rows = n / block;
+    if (rows >= 1 && d.stencil_distance >= block &&
+        block % d.elems_per_cycle[0] == 0) {
+      int32_t ext[SODA_HIP_MAX_DIM] = {1, 1, 1, 1};
+      for (int t = 0; t < d.dim - 1; ++t) ext[t] = d.tile[t];
+      ext[d.dim - 1] = (int32_t)rows;
+      int rc = soda_hip_run_device(s->dense, dout.data(), din.data(), ext,
+                                   d.iterate, hip_stream);
+      if (rc == SODA_HIP_OK) {
+        done = true;
+        s->last_mode = 1;
+      } else if (rc != SODA_HIP_ERR_INVALID) {
+        return rc;
+      }   // INVALID: this extent does not suit the dense kernels; go linear
+    }
+  }
+  if (!done) {
+    int pick = d.num_linear - 1;
+    for (int k = 0; k < d.num_linear; ++k)
+      if (n % d.linear_vec[k] == 0) { pick = k; break; }
+    if (int rc = soda_hip_run_device(s->linear[pick], dout.data(), din.data(),
+                                     ext1, d.iterate, hip_stream))
+      return rc;
+    s->last_mode = 2;
+  }
+  // 3. outputs: shifted by the stencil offset, re-interleaved
+  bank0 = 0;
+  for (int o = 0; o < d.num_outputs; ++o) {
+    const int nb = d.banks[d.num_inputs + o];
+    for (int b = 0; b < nb; ++b)
+      if (!out_banks[bank0 + b])
+        return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL output bank");
+    const void* ins[1] = {dout[o]};
+    if (int rc = soda_hip_run_device(s->wire[o], out_banks + bank0, ins, ext1, 1,
+                                     hip_stream))
+      return rc;
+    bank0 += nb;
+  }
+  return SODA_HIP_OK;
+}
+
+int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
+                             const void* const* in_banks,
+                             uint64_t coalesced_data_num) {
+  if (!s || !out_banks || !in_banks)
+    return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL argument");
+  const soda_hip_stream_desc_t& d = s->desc;
+  HIP_TRY(hipSetDevice(s->linear.back()->device));
+  int total = 0;
+  for (int t = 0; t < d.num_inputs + d.num_outputs; ++t) total += d.banks[t];
+  s->host_banks.resize(total);
+  std::vector<const void*> dev_in;
+  std::vector<void*> dev_out;
+  int slot = 0, bank = 0;
+  for (int i = 0; i < d.num_inputs; ++i)
+    for (int b = 0; b < d.banks[i]; ++b, ++slot, ++bank) {
+      const size_t bytes = (size_t)coalesced_data_num * d.elems_per_cycle[i] /
+                           d.banks[i] * d.elem_size[i];
+      if (!in_banks[bank])
+        return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL input bank");
+      if (int rc = ensure(s->host_banks[slot], bytes)) return rc;
+      HIP_TRY(hipMemcpy(s->host_banks[slot].ptr, in_banks[bank], bytes,
+                        hipMemcpyHostToDevice));
+      dev_in.push_back(s->host_banks[slot].ptr);
+    }
+  std::vector<size_t> out_bytes;
+  for (int o = 0; o < d.num_outputs; ++o)
+    for (int b = 0; b < d.banks[d.num_inputs + o]; ++b, ++slot) {
+      const int t = d.num_inputs + o;
+      const size_t bytes = (size_t)coalesced_data_num * d.elems_per_cycle[t] /
+                           d.banks[t] * d.elem_size[t];
+      if (int rc = ensure(s->host_banks[slot], bytes)) return rc;
+      dev_out.push_back(s->host_banks[slot].ptr);
+      out_bytes.push_back(bytes);
+    }
+  if (int rc = soda_hip_stream_run_device(s, dev_out.data(), dev_in.data(),
+                                          coalesced_data_num, nullptr))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  for (size_t k = 0; k < dev_out.size(); ++k) {
+    if (!out_banks[k])
+      return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL output bank");
+    HIP_TRY(hipMemcpy(out_banks[k], dev_out[k], out_bytes[k],
+                      hipMemcpyDeviceToHost));
+  }
+  return SODA_HIP_OK;
 }
 
 // -- memory / timing helpers ---------------------------------------------------

@@ -52,11 +52,15 @@ class Slab:
     self.own_begin = rank * base + min(rank, extra)
     self.own_rows = base + (1 if rank < extra else 0)
     self.own_end = self.own_begin + self.own_rows
+    # every rank must reach the same verdict, or the ones that pass block in
+    # the exchange while a neighbour has raised: judge the THINNEST slab of the
+    # decomposition (n // world rows), not this rank's own
     need = max(self.reach_lo, self.reach_hi) * exchange_every
-    if world > 1 and self.own_rows < need:
+    if world > 1 and base < need:
       raise util.InputError(
-          'slab of %d rows is thinner than the %d-row halo; use fewer GPUs or '
-          'a smaller exchange interval' % (self.own_rows, need))
+          'slabs of %d rows (%d rows over %d ranks) are thinner than the '
+          '%d-row halo; use fewer GPUs or a smaller exchange interval' %
+          (base, n, world, need))
     self.begin = self.own_begin - self.ghost_lo   # first global row held
     self.end = self.own_end + self.ghost_hi
     self.rows = self.end - self.begin

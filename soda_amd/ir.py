@@ -410,6 +410,24 @@ def get_vars(node: Node) -> List[Var]:
   return [n for n in node.walk() if isinstance(n, Var)]
 
 
+def op_count(node: Node) -> int:
+  """Arithmetic operations one evaluation of the expression costs (a rough
+  instruction count for the launch-time model of the HIP backend)."""
+  n = 0
+  for x in node.walk():
+    if isinstance(x, Chain):
+      n += len(x.operators) * (4 if x.level == 'mul_div' and any(
+          op in '/%' for op in x.operators) else 1)
+    elif isinstance(x, Unary):
+      n += len(x.ops)
+    elif isinstance(x, Call):
+      n += 8 if x.name not in ('min', 'max', 'fmin', 'fmax', 'abs', 'fabs',
+                               'select') else max(1, len(x.args) - 1)
+    elif isinstance(x, Cast):
+      n += 1
+  return n
+
+
 def flatten(node: Node) -> Node:
   """The only simplification the reference applies by default
   (`arithmetic.simplify`, core.py:131): drop no-op wrappers.  Operand order

@@ -47,7 +47,19 @@ class KernelDesc(ctypes.Structure):
               ('block', ctypes.c_int32 * 3),
               ('tile', ctypes.c_int32 * MAX_DIM),
               ('lds_bytes', ctypes.c_int32),
-              ('reserved', ctypes.c_int32)]
+              ('vec', ctypes.c_int32),
+              ('march_dim', ctypes.c_int32),
+              ('waves_along', ctypes.c_int32),
+              ('warm', ctypes.c_int32),
+              ('window_extra', ctypes.c_int32),
+              ('max_elem', ctypes.c_int32),
+              ('vgprs', ctypes.c_int32),
+              ('pipe', ctypes.c_int32),
+              ('chunk_fixed', ctypes.c_int32),
+              ('step_ns', ctypes.c_float),
+              ('warm_saved', ctypes.c_float),
+              ('bytes_per_cell', ctypes.c_float),
+              ('lane_redundancy', ctypes.c_float)]
 
 
 class PassDesc(ctypes.Structure):
@@ -93,6 +105,12 @@ API = {
         _pvp, ctypes.POINTER(ctypes.c_size_t)
     ]),
     'soda_hip_free_code': (None, [_vp]),
+    'soda_hip_plan_geometry': (ctypes.c_int, [
+        ctypes.POINTER(Plan), _pi32, _pi32, ctypes.POINTER(ctypes.c_float)
+    ]),
+    'soda_hip_plan_schedule': (ctypes.c_int, [
+        ctypes.POINTER(Plan), _pi32, _i32, _pi32
+    ]),
     'soda_hip_program_create': (ctypes.c_int, [
         _vp, ctypes.c_size_t, ctypes.POINTER(Plan), _i32, _pvp
     ]),
@@ -109,6 +127,11 @@ API = {
     ]),
     'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),
     'soda_hip_program_set_debug_buffer': (ctypes.c_int, [_vp, _vp]),
+    'soda_hip_program_calibrate': (ctypes.c_int, [_vp, _pi32, _i32, _vp]),
+    'soda_hip_program_schedule': (ctypes.c_int, [_vp, _pi32, _i32, _pi32]),
+    'soda_hip_program_pass_times': (ctypes.c_int, [
+        _vp, _pi32, ctypes.POINTER(ctypes.c_float), _pi32
+    ]),
     'soda_hip_malloc': (ctypes.c_int, [_i32, ctypes.c_size_t, _pvp]),
     'soda_hip_free': (ctypes.c_int, [_i32, _vp]),
     'soda_hip_memcpy_h2d': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
@@ -222,18 +245,21 @@ def compile_source(source: str, name: str = 'soda.hip',
   return blob
 
 
-def pass_cost(fused_iters: int) -> float:
-  """Relative time of one pass that fuses T iterations, for the scheduler in
-  soda_hip_run_device: a memory floor that rises slowly with T (more halo) or,
-  from T ~ 9, the VALU time.  Fitted to jacobi2d 8192^2 (90 / 104 / 117 / 154 us
-  at T = 1 / 4 / 8 / 12); only ratios matter, and only when several depths are
-  available (100 iterations with 12 / 8 / 4: 7 x 12 + 2 x 8, not 8 x 12 + 4)."""
-  t = float(fused_iters)
-  return max(1.0 + 0.04 * t, 0.1425 * t)
+# ns of SIMD issue time per vector instruction of a marching kernel's row step:
+# the fused kernels sustain 3.2-3.8 cycles per wave64 instruction at ~2.3 GHz
+# with their lane shifts (profiles/)
+NS_PER_VALU_OP = 1.4
 
 
-def make_plan(mod: lower.Module) -> Plan:
+def make_plan(mod: lower.Module,
+              resources: Optional[Dict[str, dict]] = None) -> Plan:
+  """The launch plan of a lowered module.  `resources` (kernel_resources of
+  the compiled code) supplies the register counts the library sizes chunks
+  from; without it chunks stay at their defaults."""
   st = mod.stencil
+  table = st.symbol_table
+  io_bytes = float(sum(table[n].size_in_bytes for n in st.input_names) +
+                   sum(table[n].size_in_bytes for n in st.output_names))
   plan = Plan()
   plan.abi_version = ABI_VERSION
   plan.dim = st.dim
@@ -261,6 +287,24 @@ def make_plan(mod: lower.Module) -> Plan:
     for d in range(MAX_DIM):
       plan.kernels[i].tile[d] = k.tile[d]
     plan.kernels[i].lds_bytes = k.lds_bytes
+    d = plan.kernels[i]
+    d.window_extra = -1
+    tune = k.tune or {}
+    d.vec = int(tune.get('vec') or 0)
+    if 'axis' in tune:                     # a marching kernel
+      d.march_dim = tune['axis'] + 1
+      d.waves_along = int(tune.get('waves_along') or 1)
+      d.warm = int(tune.get('warm') or 0)
+      extra = tune.get('window_extra')
+      d.window_extra = -1 if extra is None else int(extra)
+      d.max_elem = int(tune.get('max_elem') or 0)
+      d.pipe = int(tune.get('pipe') or 1)
+      d.chunk_fixed = 1 if tune.get('fixed') else 0
+      d.vgprs = int((resources or {}).get(k.name, {}).get('vgpr') or 0)
+      d.step_ns = float(tune.get('step_ops') or 0.0) * NS_PER_VALU_OP
+      d.warm_saved = float(tune.get('warm_saved') or 0.0)
+      d.bytes_per_cell = io_bytes
+      d.lane_redundancy = float(tune.get('lane_redundancy') or 1.0)
   passes = mod.sorted_passes()
   if len(passes) > MAX_PASSES:
     raise util.SemanticError('more than %d passes' % MAX_PASSES)
@@ -272,7 +316,7 @@ def make_plan(mod: lower.Module) -> Plan:
           'a pass of %d kernels exceeds the limit of %d' %
           (len(p.kernels), MAX_PASS_KERNELS))
     plan.passes[i].num_kernels = len(p.kernels)
-    plan.passes[i].cost = pass_cost(p.fused_iters)
+    plan.passes[i].cost = 0.0    # marching passes carry a time model instead
     for j, k in enumerate(p.kernels):
       plan.passes[i].kernel[j] = k
   return plan
@@ -329,86 +373,28 @@ def waves_per_simd(vgprs: int) -> int:
   return max(1, min(MAX_WAVES_PER_SIMD, 512 // alloc))
 
 
-def tuned_chunk(tune: dict, tile: Sequence[int], block_threads: int,
-                vgprs: int, extent: Sequence[int]) -> int:
-  """Length (cells along the marched dimension) one wave should own.
-
-  Model, fitted to tools/sweep.py --chunk runs (profiles/r01_sweeps.md): the
-  waves of a launch are dealt evenly over the 1024 SIMDs, a SIMD's waves share
-  its issue slots, and every wave pays `warm` pipeline warm-up steps on top of
-  its chunk, so
-
-      time ~ k * eff(k) * (chunk + warm),  k = max(k_min, ceil(waves / 1024))
-
-  with waves = (strips x tiles in the other dimensions) x ceil(extent/chunk).
-  k_min: one wave alone on a SIMD issues at half rate (2), and a kernel that
-  fuses few iterations is latency-bound and wants >= 4 waves per SIMD in
-  flight.  The chunk minimising this is taken (ties: the longer chunk, i.e.
-  less redundant traffic).  Examples on 8192 columns: 8192 rows, T=12 -> ~100
-  rows (one round of 3 waves/SIMD); a 1224-row slab (8-GPU run) -> ~32 rows."""
-  axis = tune['axis']
-  n = extent[axis]
-  others = 1
-  for d in range(len(extent)):
-    if d != axis:
-      others *= -(-extent[d] // tile[d])
-  waves_per_block = max(1, block_threads // 64)
-  along = max(1, tune['waves_along'])
-  across = waves_per_block // along      # waves of a block side by side
-  warm = tune['warm']
-  if tune.get('pipe', 1) > 1:
-    # Stage-pipelined blocks: the warm-up is paid once per block and the waves
-    # of a block keep each other busy, so the best chunk hardly depends on the
-    # grid: ~3.5x the warm-up (T=12, 4 waves: 96-128 rows is best or within 2 %
-    # of it on 8192 x {8192, 4296, 2248, 1224}; profiles/r01_sweep_pipe_chunk)
-    target = max(64, int(3.5 * warm))
-    chunks = max(1, -(-n // target))
-    return max(1, -(-n // chunks))
-  k_min = 4 if warm <= 12 else 2
-  simds = NUM_CUS * 4
-  cap = waves_per_simd(vgprs)      # waves per SIMD the registers allow
-  best = None
-  for chunk in range(min(n, 8), n + 1):
-    chunks = -(-n // chunk)
-    blocks = others * -(-chunks // along)
-    waves = blocks * waves_per_block
-    k = -(-waves // simds)
-    if k >= cap and waves > 0.975 * k * simds:
-      # a register-limited grid that fills the last 2-3 % of its wave slots
-      # runs slower than one a chunk-row longer that leaves them free (T=12 on
-      # 8192^2: chunk 97 = 3060 waves on 3072 slots 155-157 us; chunks 98-102 =
-      # 3024-2916 waves 151-152 us; in bench.py steps: neutral on 8192 rows,
-      # 0.555 vs 0.62 ms on the 2248-row slab of a 4-GPU run)
-      k += 1
-    k = max(k_min, k)
-    # a lone wave issues at half rate; two waves still leave dependency
-    # bubbles (measured ~20 % on the VALU-bound fused kernels)
-    cost = k * (2.0 if k == 1 else 1.2 if k == 2 else 1.0) * (chunk + warm)
-    if best is None or cost < best[0] or (cost == best[0] and chunk > best[1]):
-      best = (cost, chunk)
-  chunk = best[1]
-  if warm <= 12:
-    # latency-bound kernels (few fused iterations): more, shorter waves beat
-    # the model's pick (blur 16384^2: 32-64 rows 232 us, 132 rows 245-294 us)
-    chunk = min(chunk, 64)
-  chunks = -(-n // chunk)
-  return max(1, -(-n // chunks))          # same count, equal lengths
+def plan_geometry(plan: Plan, extent: Sequence[int]):
+  """(tile of every kernel, modelled ns of every pass) the library would use
+  for `extent` -- soda_hip_plan_geometry; no GPU needed.  Raises BackendError
+  if a kernel of the plan cannot run this extent."""
+  lib = library()
+  ext = (ctypes.c_int32 * MAX_DIM)(*(list(extent) + [1] * (MAX_DIM - len(extent))))
+  tiles = (ctypes.c_int32 * (MAX_DIM * plan.num_kernels))()
+  ns = (ctypes.c_float * plan.num_passes)()
+  check(lib.soda_hip_plan_geometry(ctypes.byref(plan), ext, tiles, ns),
+        'launch geometry for extent %s' % (tuple(extent),))
+  return ([tuple(tiles[k * MAX_DIM:(k + 1) * MAX_DIM])
+           for k in range(plan.num_kernels)], list(ns))
 
 
-BUF_WINDOW_MAX = 1 << 30    # SODA_BUF_WINDOW_MAX in csrc/soda_rt.h
-
-
-def max_chunk_for_window(tune: dict, extent: Sequence[int]) -> Optional[int]:
-  """Longest chunk whose input window (chunk + stencil reach planes of the
-  widest tensor) still fits the buffer-offset encoding of csrc/soda_rt.h;
-  None for kernels that address memory through plain pointers."""
-  extra = tune.get('window_extra')
-  if extra is None:
-    return None
-  plane = tune.get('max_elem', 8)
-  for d in range(tune['axis']):
-    plane *= extent[d]
-  return BUF_WINDOW_MAX // plane - extra
+def plan_schedule(plan: Plan, extent: Sequence[int], iterate: int):
+  """How many times each pass runs for `iterate` iterations on `extent`."""
+  lib = library()
+  ext = (ctypes.c_int32 * MAX_DIM)(*(list(extent) + [1] * (MAX_DIM - len(extent))))
+  count = (ctypes.c_int32 * plan.num_passes)()
+  check(lib.soda_hip_plan_schedule(ctypes.byref(plan), ext, iterate, count),
+        'schedule of %d iterations' % iterate)
+  return list(count)
 
 
 def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
@@ -509,18 +495,20 @@ class Program:
 
   def __init__(self, stencil: core.Stencil,
                opts: Optional[lower.LowerOptions] = None, device: int = 0,
-               extent: Optional[Sequence[int]] = None):
+               extent: Optional[Sequence[int]] = None,
+               calibrate: bool = False):
     self.stencil = stencil
     self.opts = resolve_options(stencil, opts, extent)   # never the caller's
     self.device = device
     self.module = lower.lower(stencil, self.opts)
-    self.plan = make_plan(self.module)
     self.code = compile_source(self.module.source,
                                '%s.hip' % stencil.app_name)
     self.resources = kernel_resources(self.code)
-    self.tuned_for = None
+    # launch geometry (chunk lengths, pass schedule) is the library's, decided
+    # per run from the extent it is given and the register counts in the plan
+    self.plan = make_plan(self.module, self.resources)
     if extent is not None:
-      self.tune(extent)
+      self.geometry(extent)            # fail early if it cannot run
     self._lib = library()
     self._handle = ctypes.c_void_p()
     check(
@@ -528,33 +516,53 @@ class Program:
                                           ctypes.byref(self.plan), device,
                                           ctypes.byref(self._handle)),
         'loading `%s` on GPU %d' % (stencil.app_name, device))
+    if calibrate and extent is not None:
+      self.calibrate(extent)
 
   # -- launch geometry ------------------------------------------------------
-  def tune(self, extent: Sequence[int]) -> None:
-    """Sizes every marching kernel's chunk for `extent` on this GPU (plan
-    only; the code object is unchanged).  Must precede program creation."""
-    for i, k in enumerate(self.module.kernels):
-      if not k.tune or k.tune.get('fixed'):
-        continue
-      res = self.resources.get(k.name)
-      if not res:
-        continue
-      axis = k.tune['axis']
-      tile = list(k.tile)
-      per_wave = tuned_chunk(k.tune, tile, k.block[0] * k.block[1] * k.block[2],
-                             res['vgpr'], extent)
-      limit = max_chunk_for_window(k.tune, extent)
-      if limit is not None:
-        if limit < 1:
-          raise util.InputError(
-              '%s: one plane of extent %s exceeds the 1 GiB buffer window of '
-              'the marching kernels; use --hip-strategy direct' %
-              (k.name, tuple(extent)))
-        per_wave = min(per_wave, limit)
-      tile[axis] = per_wave * k.tune['waves_along']
-      k.tile = tuple(tile)
-      self.plan.kernels[i].tile[axis] = tile[axis]
-    self.tuned_for = tuple(extent)
+  def geometry(self, extent: Sequence[int]):
+    """What a run on `extent` uses: ({kernel name: tile}, {fused iterations
+    of a pass: modelled microseconds})."""
+    tiles, ns = plan_geometry(self.plan, extent)
+    passes = self.module.sorted_passes()
+    return ({k.name: t[:self.stencil.dim]
+             for k, t in zip(self.module.kernels, tiles)},
+            {p.fused_iters: v / 1e3 for p, v in zip(passes, ns)})
+
+  def calibrate(self, extent: Sequence[int], launches: int = 4,
+                stream: int = 0) -> Dict[int, float]:
+    """Times one launch of every pass on `extent` on the GPU (a few ms, once)
+    so that runs on this extent are scheduled by the clock; returns {fused
+    iterations: microseconds}."""
+    ext = (ctypes.c_int32 * MAX_DIM)(*(list(extent) +
+                                        [1] * (MAX_DIM - len(extent))))
+    check(self._lib.soda_hip_program_calibrate(self._handle, ext, launches,
+                                               ctypes.c_void_p(stream)),
+          'calibrating `%s`' % self.stencil.app_name)
+    return self.pass_times(extent)[0]
+
+  def pass_times(self, extent: Sequence[int]):
+    """({fused iterations: microseconds per launch}, measured?)"""
+    ext = (ctypes.c_int32 * MAX_DIM)(*(list(extent) +
+                                        [1] * (MAX_DIM - len(extent))))
+    ns = (ctypes.c_float * self.plan.num_passes)()
+    measured = ctypes.c_int32(0)
+    check(self._lib.soda_hip_program_pass_times(self._handle, ext, ns,
+                                                ctypes.byref(measured)),
+          'pass_times')
+    return ({p.fused_iters: v / 1e3
+             for p, v in zip(self.module.sorted_passes(), ns)},
+            bool(measured.value))
+
+  def schedule(self, extent: Sequence[int], iterate: int) -> Dict[int, int]:
+    """{fused iterations of a pass: launches} for `iterate` iterations."""
+    ext = (ctypes.c_int32 * MAX_DIM)(*(list(extent) +
+                                        [1] * (MAX_DIM - len(extent))))
+    count = (ctypes.c_int32 * self.plan.num_passes)()
+    check(self._lib.soda_hip_program_schedule(self._handle, ext, iterate,
+                                              count), 'schedule')
+    return {p.fused_iters: c
+            for p, c in zip(self.module.sorted_passes(), count) if c}
 
   # -- lifecycle -----------------------------------------------------------
   def close(self) -> None:
@@ -578,21 +586,8 @@ class Program:
   def _check_extent(self, extent: Sequence[int]) -> None:
     if len(extent) != self.stencil.dim:
       raise util.InputError('extent must have %d entries' % self.stencil.dim)
-    if self.opts.vec > 1 and extent[0] % self.opts.vec:
-      raise util.InputError(
-          'this program was built for rows that are a multiple of %d cells; '
-          'rebuild it for extent %s' % (self.opts.vec, tuple(extent)))
-    for k in self.module.kernels:
-      limit = max_chunk_for_window(k.tune, extent) if k.tune else None
-      if limit is not None:
-        axis = k.tune['axis']
-        per_wave = k.tile[axis] // max(1, k.tune['waves_along'])
-        if per_wave > limit:
-          raise util.InputError(
-              '%s: chunks of %d planes of extent %s exceed the 1 GiB buffer '
-              'window of the marching kernels; rebuild the program for this '
-              'extent (or use --hip-strategy direct)' %
-              (k.name, per_wave, tuple(extent)))
+    # (vector width and buffer-window limits are the library's to check:
+    # soda_hip_plan_geometry, also behind every run entry of the C ABI)
 
   # -- device-resident arrays (the <app>_kernel analogue) ------------------
   def run_device(self, outputs: Sequence[int], inputs: Sequence[int],

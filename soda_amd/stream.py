@@ -125,7 +125,7 @@ class WireLayout:
     self.stencil_offset = stencil_offsets(st)                          # :401-408
 
 
-_WIRE_SRC = '''
+_WIRE_SRC = """
 // bank k %% NB, index k / NB  <->  stream position k   (reference
 // docs/data-layout.md "Multi-Bank"; frt/host.py:241-246, 422-424)
 extern "C" __global__ void __launch_bounds__(256) %(name)s(soda_hip_kargs_t a) {
@@ -133,11 +133,165 @@ extern "C" __global__ void __launch_bounds__(256) %(name)s(soda_hip_kargs_t a) {
   if (k >= a.extent[0]) return;
 %(body)s
 }
-'''
+"""
+
+# the library's mirror of soda_hip_stream_desc_t
+class StreamDesc(ctypes.Structure):
+  _fields_ = [('dim', ctypes.c_int32), ('num_inputs', ctypes.c_int32),
+              ('num_outputs', ctypes.c_int32), ('iterate', ctypes.c_int32),
+              ('tile', ctypes.c_int32 * runtime.MAX_DIM),
+              ('stencil_distance', ctypes.c_int32),
+              ('banks', ctypes.c_int32 * runtime.MAX_TENSORS),
+              ('elem_size', ctypes.c_int32 * runtime.MAX_TENSORS),
+              ('elems_per_cycle', ctypes.c_int32 * runtime.MAX_TENSORS),
+              ('shift', ctypes.c_int32 * runtime.MAX_TENSORS),
+              ('num_linear', ctypes.c_int32),
+              ('linear_vec', ctypes.c_int32 * 4)]
+
+
+class ProgramSpec:
+  """One code object + plan of the wire-format kernel (what the C++ the
+  `--hip-wire-kernel` generator prints embeds, and what StreamProgram loads)."""
+
+  def __init__(self, tag: str, source: str, plan: 'runtime.Plan',
+               kernel_names: Sequence[str]):
+    self.tag, self.source, self.plan = tag, source, plan
+    self.kernel_names = list(kernel_names)
+
+
+def _copy_plan(name: str, n_in: int, n_out: int, elem: int) -> 'runtime.Plan':
+  plan = runtime.Plan()
+  plan.abi_version = runtime.ABI_VERSION
+  plan.dim = 1
+  plan.num_inputs, plan.num_outputs = n_in, n_out
+  for i in range(n_in + n_out):
+    plan.elem_size[i] = elem
+  plan.num_kernels = 1
+  plan.kernels[0].name = name.encode()
+  plan.kernels[0].block[0] = 256
+  plan.kernels[0].block[1] = plan.kernels[0].block[2] = 1
+  plan.kernels[0].tile[0] = 256
+  for d in range(1, runtime.MAX_DIM):
+    plan.kernels[0].tile[d] = 1
+  plan.kernels[0].window_extra = -1
+  plan.num_passes = 1
+  plan.passes[0].fused_iters = 1
+  plan.passes[0].num_kernels = 1
+  return plan
+
+
+def input_shifts(stencil: core.Stencil) -> Dict[str, int]:
+  """Elements the reference host delays every input stream by (its
+  `produce_offset`, frt/host.py:241-246).  Zero for a single input (the
+  reference pins input 0 at 0, core.py:374); for several inputs the offsets
+  come out of the reference's ILP (core.py:371-426), restated in
+  core.produce_offsets."""
+  if len(stencil.input_names) == 1:
+    return {stencil.input_names[0]: 0}
+  return stencil.produce_offsets()
+
+
+def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None):
+  """(StreamDesc, {tag: ProgramSpec}) of `<app>_kernel` for `stencil`.  Tags:
+  `dense` (optional), `linear<V>`, `unwire_<input>`, `wire_<output>`."""
+  if stencil.param_stmts:
+    raise util.SemanticError('stream mode does not support param tensors')
+  if stencil.preserve_border:
+    raise util.SemanticError(
+        'stream mode does not support border: preserve (tile edges are not '
+        'grid borders)')
+  st = stencil
+  table = st.symbol_table
+  flat = linearize(st)
+  banks = {s.name: len(s.dram) for s in st.input_stmts + st.output_stmts}
+  offsets = stencil_offsets(st)
+  shifts = input_shifts(st)
+  names = list(st.input_names) + list(st.output_names)
+  desc = StreamDesc()
+  desc.dim = st.dim
+  desc.num_inputs, desc.num_outputs = len(st.input_names), len(st.output_names)
+  desc.iterate = st.iterate
+  for d in range(st.dim - 1):
+    desc.tile[d] = st.tile_size[d]
+  desc.stencil_distance = st.stencil_distance if st.dim >= 2 else 0
+  for t, n in enumerate(names):
+    desc.banks[t] = banks[n]
+    desc.elem_size[t] = table[n].size_in_bytes
+    desc.elems_per_cycle[t] = st.burst_width // table[n].width_in_bits * banks[n]
+    desc.shift[t] = shifts[n] if n in shifts else offsets[n]
+  specs: Dict[str, ProgramSpec] = {}
+
+  def program_spec(tag, sten, opts, extent):
+    opts = runtime.resolve_options(sten, opts, extent)
+    mod = lower.lower(sten, opts)
+    res = runtime.kernel_resources(
+        runtime.compile_source(mod.source, '%s.hip' % sten.app_name))
+    specs[tag] = ProgramSpec(tag, mod.source, runtime.make_plan(mod, res),
+                             [k.name for k in mod.kernels])
+
+  # the linearised 1-D program, widest vector first, always ending in 1
+  vecs = []
+  v = lower.default_vec(flat)
+  while v >= 1:
+    vecs.append(v)
+    v //= 2
+  vecs = vecs[:4] if vecs[:4][-1] == 1 else vecs[:3] + [1]
+  desc.num_linear = len(vecs)
+  for k, v in enumerate(vecs):
+    desc.linear_vec[k] = v
+    program_spec('linear%d' % v, flat,
+                 lower.LowerOptions(strategy='direct', vec=v), None)
+  # the original n-D program on the dense view of the stream; narrow tiles
+  # leave most of a 64-lane x V-wide marching strip idle and the linear form
+  # wins (heat3d 32 x 32 tiles: 0.50 vs 0.79 ms)
+  if dense is None:
+    dense = st.dim >= 2 and st.tile_size[0] >= StreamProgram.DENSE_MIN_TILE0
+  if dense and st.dim >= 2:
+    try:
+      program_spec('dense', st, lower.LowerOptions(),
+                   tuple(st.tile_size[:-1]) + (1 << 20,))
+    except util.SodaError:
+      pass
+  chunks = [lower.runtime_text()]
+  copies = []
+  for s_ in st.input_stmts:
+    nb, ct = banks[s_.name], table[s_.name].c_type
+    shift = shifts[s_.name]
+    if nb == 1 and shift == 0:
+      continue
+    name = 'soda_unwire_%s' % s_.name
+    body = ['  %s* __restrict__ dense = (%s*)a.buf[%d];' % (ct, ct, nb),
+            '  const int64_t src = k + %d;   // the host delayed this tensor' %
+            shift,
+            '  const %s* bank = (const %s*)a.buf[src %% %d];' % (ct, ct, nb),
+            '  dense[k] = src < a.extent[0] ? bank[src / %d] : (%s)0;' %
+            (nb, ct)]
+    chunks.append(_WIRE_SRC % dict(name=name, body='\n'.join(body)))
+    copies.append(('unwire_%s' % s_.name, name, nb, 1,
+                   table[s_.name].size_in_bytes))
+  for s_ in st.output_stmts:
+    nb, ct = banks[s_.name], table[s_.name].c_type
+    off = offsets[s_.name]
+    name = 'soda_wire_%s' % s_.name
+    body = ['  const %s* __restrict__ dense = (const %s*)a.buf[0];' % (ct, ct),
+            '  %s* bank = (%s*)a.buf[1 + k %% %d];' % (ct, ct, nb),
+            '  bank[k / %d] = k >= %d ? dense[k - %d] : (%s)0;' %
+            (nb, off, off, ct)]
+    chunks.append(_WIRE_SRC % dict(name=name, body='\n'.join(body)))
+    copies.append(('wire_%s' % s_.name, name, 1, nb,
+                   table[s_.name].size_in_bytes))
+  source = '\n'.join(chunks)
+  for tag, name, n_in, n_out, elem in copies:
+    specs[tag] = ProgramSpec(tag, source, _copy_plan(name, n_in, n_out, elem),
+                             [name])
+  return desc, specs
 
 
 class StreamProgram:
-  """`<app>_kernel` for one program: banked wire streams in, banked out."""
+  """`<app>_kernel` for one program: banked wire streams in, banked out.  A
+  thin Python handle on the library's stream object (soda_hip_stream_*): the
+  per-call sequence -- un-interleave, program, shift + re-interleave -- runs
+  behind the C ABI."""
 
   # narrower tiles leave most of a 64-lane x V-wide marching strip idle and the
   # linear form (`direct` kernels) wins (heat3d 32x32 tiles: 0.50 vs 0.79 ms)
@@ -148,224 +302,95 @@ class StreamProgram:
     """`dense`: None = use the n-D marching kernels when the stream allows it
     and the tile is wide enough to fill them, True = whenever the stream
     allows it, False = always the linear form."""
-    if stencil.param_stmts:
-      raise util.SemanticError('stream mode does not support param tensors')
-    if stencil.preserve_border:
-      raise util.SemanticError(
-          'stream mode does not support border: preserve (tile edges are not '
-          'grid borders)')
     self.stencil = stencil
     self.device = device
-    self.flat = linearize(stencil)
-    table = stencil.symbol_table
+    self.desc, self.specs = stream_specs(stencil, dense)
     self.banks = {s.name: len(s.dram)
                   for s in stencil.input_stmts + stencil.output_stmts}
     self.stencil_offset = stencil_offsets(stencil)   # a program constant
-    self._lib = runtime.library()
-    # two ways of running the program on the de-interleaved stream:
-    #  * as the ORIGINAL n-D program on the stream viewed as a dense array of
-    #    extent (tile_size..., rows) -- tiles are whole rows laid end to end --
-    #    with the fast marching kernels (built on first use);
-    #  * as the linearised 1-D program (always valid, `direct` kernels).
-    self._linear = {}      # cells per thread -> Program of the 1-D form
-    self._linear_program(1)
-    self._dense = None
-    if dense is None:
-      dense = stencil.dim >= 2 and stencil.tile_size[0] >= self.DENSE_MIN_TILE0
-    self._dense_failed = not dense
-    self.last_mode = None
-    # wire <-> dense copy kernels, one per tensor
-    chunks = [lower.runtime_text()]
-    self._copy = {}
-    for s in stencil.input_stmts:
-      nb, ct = self.banks[s.name], table[s.name].c_type
-      name = 'soda_unwire_%s' % s.name
-      body = ['  %s* __restrict__ dense = (%s*)a.buf[%d];' % (ct, ct, nb),
-              '  const %s* bank = (const %s*)a.buf[k %% %d];' % (ct, ct, nb),
-              '  dense[k] = bank[k / %d];' % nb]
-      chunks.append(_WIRE_SRC % dict(name=name, body='\n'.join(body)))
-      self._copy[s.name] = (name, nb, 1, table[s.name].size_in_bytes)
-    for s in stencil.output_stmts:
-      nb, ct = self.banks[s.name], table[s.name].c_type
-      off = self.stencil_offset[s.name]
-      name = 'soda_wire_%s' % s.name
-      body = ['  const %s* __restrict__ dense = (const %s*)a.buf[0];' % (ct, ct),
-              '  %s* bank = (%s*)a.buf[1 + k %% %d];' % (ct, ct, nb),
-              '  bank[k / %d] = k >= %d ? dense[k - %d] : (%s)0;' %
-              (nb, off, off, ct)]
-      chunks.append(_WIRE_SRC % dict(name=name, body='\n'.join(body)))
-      self._copy[s.name] = (name, 1, nb, table[s.name].size_in_bytes)
-    code = runtime.compile_source('\n'.join(chunks),
-                                  '%s_wire.hip' % stencil.app_name)
-    self._handles = {}
-    for tensor, (name, n_in, n_out, elem) in self._copy.items():
-      plan = runtime.Plan()
-      plan.abi_version = runtime.ABI_VERSION
-      plan.dim = 1
-      plan.num_inputs, plan.num_outputs = n_in, n_out
-      for i in range(n_in + n_out):
-        plan.elem_size[i] = elem
-      plan.num_kernels = 1
-      plan.kernels[0].name = name.encode()
-      plan.kernels[0].block[0] = 256
-      plan.kernels[0].block[1] = plan.kernels[0].block[2] = 1
-      plan.kernels[0].tile[0] = 256
-      for d in range(1, runtime.MAX_DIM):
-        plan.kernels[0].tile[d] = 1
-      plan.num_passes = 1
-      plan.passes[0].fused_iters = 1
-      plan.passes[0].num_kernels = 1
+    self._lib = lib = runtime.library()
+    lib.soda_hip_stream_create.restype = ctypes.c_int
+    lib.soda_hip_stream_run_device.restype = ctypes.c_int
+    lib.soda_hip_stream_run_device.argtypes = [
+        ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_void_p]
+    lib.soda_hip_stream_run_host.restype = ctypes.c_int
+    lib.soda_hip_stream_run_host.argtypes = [
+        ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64]
+    lib.soda_hip_stream_last_mode.argtypes = [ctypes.c_void_p]
+    lib.soda_hip_stream_destroy.argtypes = [ctypes.c_void_p]
+    self._programs: Dict[str, ctypes.c_void_p] = {}
+    codes = {}
+    for tag, spec in self.specs.items():
+      if spec.source not in codes:
+        codes[spec.source] = runtime.compile_source(
+            spec.source, '%s_%s.hip' % (stencil.app_name, tag))
+      code = codes[spec.source]
       h = ctypes.c_void_p()
       runtime.check(
-          self._lib.soda_hip_program_create(code, len(code), ctypes.byref(plan),
-                                            device, ctypes.byref(h)),
-          'loading %s' % name)
-      self._handles[tensor] = (h, plan)
-    self._scratch = {}
+          lib.soda_hip_program_create(code, len(code), ctypes.byref(spec.plan),
+                                      device, ctypes.byref(h)),
+          'loading %s of `%s`' % (tag, stencil.app_name))
+      self._programs[tag] = h
+    d = self.desc
+    lin = (ctypes.c_void_p * d.num_linear)(*[
+        self._programs['linear%d' % d.linear_vec[k]]
+        for k in range(d.num_linear)])
+    unw = (ctypes.c_void_p * d.num_inputs)(*[
+        self._programs.get('unwire_%s' % n) for n in stencil.input_names])
+    wir = (ctypes.c_void_p * d.num_outputs)(*[
+        self._programs['wire_%s' % n] for n in stencil.output_names])
+    self._handle = ctypes.c_void_p()
+    runtime.check(
+        lib.soda_hip_stream_create(ctypes.byref(d), self._programs.get('dense'),
+                                   lin, unw, wir, ctypes.byref(self._handle)),
+        'stream object of `%s`' % stencil.app_name)
 
-  def _linear_program(self, vec: int) -> 'runtime.Program':
-    if vec not in self._linear:
-      self._linear[vec] = runtime.Program(
-          self.flat, lower.LowerOptions(strategy='direct', vec=vec),
-          device=self.device)
-    return self._linear[vec]
+  @property
+  def last_mode(self) -> Optional[str]:
+    return {1: 'dense', 2: 'linear'}.get(
+        self._lib.soda_hip_stream_last_mode(self._handle))
 
-  # -- device memory helpers -----------------------------------------------
-  def _dev(self, key, nbytes):
-    cur = self._scratch.get(key)
-    if cur and cur[1] >= nbytes:
-      return cur[0]
-    if cur:
-      self._lib.soda_hip_free(self.device, ctypes.c_void_p(cur[0]))
-    p = ctypes.c_void_p()
-    runtime.check(self._lib.soda_hip_malloc(self.device, nbytes,
-                                            ctypes.byref(p)), 'malloc')
-    self._scratch[key] = (p.value, nbytes)
-    return p.value
-
-  def _launch(self, tensor, outs, ins, n, stream):
-    h, _ = self._handles[tensor]
-    o = (ctypes.c_void_p * len(outs))(*outs)
-    i = (ctypes.c_void_p * len(ins))(*ins)
-    ext = (ctypes.c_int32 * 1)(n)
-    runtime.check(self._lib.soda_hip_run_device(h, o, i, ext, 1,
-                                                ctypes.c_void_p(stream)),
-                  'wire copy of %s' % tensor)
+  def _flat(self, banks_by_name, names) -> 'ctypes.Array':
+    ptrs = []
+    for n in names:
+      if len(banks_by_name[n]) != self.banks[n]:
+        raise util.InputError('%s has %d banks' % (n, self.banks[n]))
+      ptrs.extend(banks_by_name[n])
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
 
   # -- <app>_kernel on device-resident banks -------------------------------
   def run_banked_device(self, out_banks: Dict[str, List[int]],
                         in_banks: Dict[str, List[int]],
                         coalesced_data_num: int, stream: int = 0) -> None:
     st = self.stencil
-    table = st.symbol_table
-    epc = {n: st.burst_width // table[n].width_in_bits * self.banks[n]
-           for n in self.banks}
-    n_elems = {n: coalesced_data_num * epc[n] for n in self.banks}
-    n = n_elems[st.input_names[0]]
-    if any(v != n for v in n_elems.values()):
-      raise util.InputError(
-          'stream mode needs every tensor to move the same number of elements '
-          'per cycle (burst width / element width x banks)')
-    if n >= 2**31:
-      raise util.InputError('stream longer than 2^31 elements')
-    dense_in, dense_out = [], []
-    for name in st.input_names:
-      if len(in_banks[name]) != self.banks[name]:
-        raise util.InputError('%s has %d banks' % (name, self.banks[name]))
-      if self.banks[name] == 1:
-        # one bank: the bank IS the dense stream, and inputs are never written
-        dense_in.append(in_banks[name][0])
-        continue
-      d = self._dev(('in', name), n * table[name].size_in_bytes)
-      self._launch(name, [d], in_banks[name], n, stream)
-      dense_in.append(d)
-    for name in st.output_names:
-      dense_out.append(self._dev(('out', name), n * table[name].size_in_bytes))
-    if self._run_dense(dense_out, dense_in, n, epc[st.input_names[0]], stream):
-      self.last_mode = 'dense'
-    else:
-      vec = lower.default_vec(self.flat)
-      while vec > 1 and n % vec:
-        vec //= 2
-      self._linear_program(vec).run_device(dense_out, dense_in, (n,),
-                                           st.iterate, stream)
-      self.last_mode = 'linear'
-    for name, d in zip(st.output_names, dense_out):
-      if len(out_banks[name]) != self.banks[name]:
-        raise util.InputError('%s has %d banks' % (name, self.banks[name]))
-      self._launch(name, out_banks[name], [d], n, stream)
-
-  def _run_dense(self, dense_out, dense_in, n: int, epc: int,
-                 stream: int) -> bool:
-    """Runs the original program on the stream seen as (tile..., rows).  Valid
-    when the stream really is such an array:
-      * every tile starts on a row-block boundary.  A tile occupies
-        round_up(block * extent_last, epc) elements (frt/host.py:137-142), so
-        this holds for any extent iff block % epc == 0 (the kernel is not told
-        the extent, only the cycle count);
-      * the void tail the host appends (kStencilDistance elements,
-        frt/host.py:151-162) is at least one row block, so that the partial
-        last row the view drops holds no cell of any tile.
-    Cells whose taps cross a tile edge read zeros here and wrapped neighbours
-    in the linear form: both are outside the valid region."""
-    st = self.stencil
-    if st.dim < 2 or self._dense_failed:
-      return False
-    block = 1
-    for t in st.tile_size[:-1]:
-      block *= t
-    rows = n // block
-    if rows < 1 or st.stencil_distance < block or block % epc:
-      return False
-    extent = tuple(st.tile_size[:-1]) + (rows,)
-    if self._dense is None:
-      try:
-        self._dense = runtime.Program(st, lower.LowerOptions(),
-                                      device=self.device, extent=extent)
-      except util.SodaError:
-        self._dense_failed = True
-        return False
-    self._dense.run_device(dense_out, dense_in, extent, st.iterate, stream)
-    return True
+    runtime.check(
+        self._lib.soda_hip_stream_run_device(
+            self._handle, self._flat(out_banks, st.output_names),
+            self._flat(in_banks, st.input_names), coalesced_data_num,
+            ctypes.c_void_p(stream)), '%s_kernel' % st.app_name)
 
   # -- <app>_kernel on host banks (what SODA_CPP_BINDING links against) ------
   def run_banked_host(self, out_banks: Dict[str, list], in_banks: Dict[str, list],
                       coalesced_data_num: int) -> None:
     """numpy arrays per bank, sized as the reference host allocates them."""
-    lib = self._lib
-    dev_in, dev_out = {}, {}
-    for name, arrs in in_banks.items():
-      dev_in[name] = []
-      for b, a in enumerate(arrs):
-        p = self._dev(('hin', name, b), a.nbytes)
-        runtime.check(lib.soda_hip_memcpy_h2d(ctypes.c_void_p(p),
-                                              ctypes.c_void_p(a.ctypes.data),
-                                              a.nbytes, None), 'h2d')
-        dev_in[name].append(p)
-    for name, arrs in out_banks.items():
-      dev_out[name] = [self._dev(('hout', name, b), a.nbytes)
-                       for b, a in enumerate(arrs)]
-    self.run_banked_device(dev_out, dev_in, coalesced_data_num)
-    runtime.synchronize()
-    for name, arrs in out_banks.items():
-      for p, a in zip(dev_out[name], arrs):
-        runtime.check(lib.soda_hip_memcpy_d2h(ctypes.c_void_p(a.ctypes.data),
-                                              ctypes.c_void_p(p), a.nbytes,
-                                              None), 'd2h')
+    st = self.stencil
+    outs = {n: [a.ctypes.data for a in arrs] for n, arrs in out_banks.items()}
+    ins = {n: [a.ctypes.data for a in arrs] for n, arrs in in_banks.items()}
+    runtime.check(
+        self._lib.soda_hip_stream_run_host(
+            self._handle, self._flat(outs, st.output_names),
+            self._flat(ins, st.input_names), coalesced_data_num),
+        '%s_kernel' % st.app_name)
 
   def close(self) -> None:
-    for h, _ in getattr(self, '_handles', {}).values():
+    if getattr(self, '_handle', None):
+      self._lib.soda_hip_stream_destroy(self._handle)
+      self._handle = None
+    for h in getattr(self, '_programs', {}).values():
       self._lib.soda_hip_program_destroy(h)
-    self._handles = {}
-    for p, _ in getattr(self, '_scratch', {}).values():
-      self._lib.soda_hip_free(self.device, ctypes.c_void_p(p))
-    self._scratch = {}
-    for prog in getattr(self, '_linear', {}).values():
-      prog.close()
-    self._linear = {}
-    if getattr(self, '_dense', None):
-      self._dense.close()
-      self._dense = None
+    self._programs = {}
 
   def __del__(self):
     try:

@@ -125,24 +125,91 @@ def test_march3d_geometry_for_heat3d():
 
 
 def test_chunk_is_sized_from_the_code_objects_registers(built, tmp_path):
+  """Launch geometry is the LIBRARY's (soda_hip_plan_geometry, no GPU needed):
+  chunk lengths follow the extent and the compiled kernels' register counts so
+  that the grid is whole rounds of waves on the 1024 SIMDs."""
   from soda_amd import runtime
   from soda_amd.codegen.hip import lower
   stencil = core.from_file(soda_path('jacobi2d.soda'))
-  opts = lower.LowerOptions(fuse=(12,), vec=4)
+  opts = lower.LowerOptions(fuse=(12,), vec=4, peel=0)
   mod = lower.lower(stencil, opts)
   code = runtime.compile_source(mod.source, 'j.hip', cache_dir=str(tmp_path))
   res = runtime.kernel_resources(code)
   assert set(res) == {k.name for k in mod.kernels}
-  for k in mod.kernels:
+  plan = runtime.make_plan(mod, res)
+  tiles, ns = runtime.plan_geometry(plan, (8192, 8192))
+  for k, tile in zip(mod.kernels, tiles):
     assert 16 <= res[k.name]['vgpr'] <= 256 and res[k.name]['scratch'] == 0
-    chunk = runtime.tuned_chunk(k.tune, k.tile, 64, res[k.name]['vgpr'],
-                                (8192, 8192))
-    waves = -(-8192 // k.tile[0]) * -(-8192 // chunk)
+    waves = -(-8192 // tile[0]) * -(-8192 // tile[1])
     slots = 1024 * runtime.waves_per_simd(res[k.name]['vgpr'])
-    assert chunk >= 64 and waves <= max(slots, 8192 // 64 * 36)
+    assert tile[0] == k.tile[0] and tile[1] >= 64
+    assert waves <= max(slots, 8192 // 64 * 36)
+  assert all(v > 0 for v in ns)
+  # a 1224-row slab of the same grid (one GPU's share of an 8-GPU run): far
+  # shorter chunks, the same strips
+  slab_tiles, slab_ns = runtime.plan_geometry(plan, (8192, 1224))
+  assert slab_tiles[0][0] == tiles[0][0] and slab_tiles[0][1] < 40
+  assert slab_ns[0] < ns[0] / 3
+  # without register counts the chunk stays as generated
+  bare = runtime.make_plan(mod)
+  assert runtime.plan_geometry(bare, (8192, 8192))[0][0][:2] == mod.kernels[
+      0].tile[:2]
   assert runtime.waves_per_simd(64) == 8 and runtime.waves_per_simd(65) == 7
   assert runtime.waves_per_simd(128) == 4 and runtime.waves_per_simd(167) == 3
   assert runtime.waves_per_simd(300) == 1
+
+
+def test_schedule_follows_the_extent(built, tmp_path):
+  """The multiset of passes that advances `iterate` iterations is chosen per
+  extent from the library's time model (soda_hip_plan_schedule): always adds
+  up, deepest fusion on the full grid, and never the one-iteration pass where
+  a fused one can do the work."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=100)
+  opts = runtime.resolve_options(stencil, lower.LowerOptions(fuse=(12, 8, 4)),
+                                 (8192, 8192))
+  mod = lower.lower(stencil, opts)
+  code = runtime.compile_source(mod.source, 'j.hip', cache_dir=str(tmp_path))
+  plan = runtime.make_plan(mod, runtime.kernel_resources(code))
+  depth = [p.fused_iters for p in mod.sorted_passes()]
+  assert depth == [12, 8, 4, 1]
+  for extent in ((8192, 8192), (8192, 1224), (8192, 200), (640, 480)):
+    for iterate in (1, 7, 100, 1000):
+      count = runtime.plan_schedule(plan, extent, iterate)
+      assert sum(c * t for c, t in zip(count, depth)) == iterate
+      if iterate >= 4:
+        assert count[-1] <= 3
+  full = runtime.plan_schedule(plan, (8192, 8192), 100)
+  assert full[0] >= 6          # mostly the 12-deep pass on the full grid
+
+
+def test_library_refuses_extents_a_kernel_cannot_run(built, tmp_path):
+  """The constraints the kernels were generated under are checked behind the
+  C ABI, not only in the Python wrapper: rows that are not a multiple of the
+  vector width, planes too large for the 1 GiB buffer window."""
+  from soda_amd import runtime, util
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('jacobi2d.soda'))
+  mod = lower.lower(stencil, lower.LowerOptions(fuse=(), vec=4))
+  code = runtime.compile_source(mod.source, 'j.hip', cache_dir=str(tmp_path))
+  plan = runtime.make_plan(mod, runtime.kernel_resources(code))
+  runtime.plan_geometry(plan, (8192, 64))
+  with pytest.raises(util.BackendError, match='multiple of 4 cells'):
+    runtime.plan_geometry(plan, (8190, 64))
+  direct = lower.lower(stencil, lower.LowerOptions(strategy='direct', vec=4))
+  dplan = runtime.make_plan(direct)
+  with pytest.raises(util.BackendError, match='multiple of 4 cells'):
+    runtime.plan_geometry(dplan, (8190, 64))
+  heat = core.from_file(soda_path('heat3d.soda'))
+  hmod = lower.lower(heat, lower.LowerOptions(fuse=(), vec=4))
+  hcode = runtime.compile_source(hmod.source, 'h.hip', cache_dir=str(tmp_path))
+  hplan = runtime.make_plan(hmod, runtime.kernel_resources(hcode))
+  # 4096 x 4096 floats = 64 MiB per plane -> 16 planes per GiB, 2 of them halo
+  tiles, _ = runtime.plan_geometry(hplan, (4096, 4096, 100))
+  assert tiles[0][2] <= 14
+  with pytest.raises(util.BackendError, match='1 GiB buffer window'):
+    runtime.plan_geometry(hplan, (32768, 16384, 9))
 
 
 def test_vector_width_follows_row_length():
@@ -241,20 +308,6 @@ def test_backend_plugin_surface():
   assert one_shot.nt_store and not one_shot.nt_load
   stencil = core.from_file(soda_path('jacobi2d.soda'))
   assert hip.default_extent(stencil) == [32, 6]   # frt/host.py:454-461
-
-
-def test_buffer_window_limits_the_chunk():
-  """Marching kernels address a wave's window of a tensor with 32-bit buffer
-  offsets (csrc/soda_rt.h): the host caps the chunk so the window stays within
-  1 GiB, and refuses extents whose single plane does not fit."""
-  from soda_amd import runtime
-  tune = dict(axis=2, window_extra=2, max_elem=4)
-  # 4096 x 4096 floats = 64 MiB per plane -> 16 planes per GiB, 2 of them halo
-  assert runtime.max_chunk_for_window(tune, (4096, 4096, 100)) == 14
-  assert runtime.max_chunk_for_window(tune, (32768, 16384, 9)) < 1
-  assert runtime.max_chunk_for_window(dict(axis=1), (8192, 8192)) is None
-  tune2 = dict(axis=1, window_extra=26, max_elem=4)
-  assert runtime.max_chunk_for_window(tune2, (8192, 8192)) == 32768 - 26
 
 
 def test_march_loop_body_is_branch_free():

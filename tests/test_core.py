@@ -238,3 +238,45 @@ output dram 1 float: b(0, 0) = a(0, 9) + 2.0f * (%s) + (%s) * 3.0f + a(1, 9)
   assert str(out.operands[0].operands[1]) == '2.0f'       # coefficient last
   assert [str(o) for o in out.operands[1:]] == [
       'a(0, 9)', 'a(1, 9)', 'cr_var_0(0, 0)']
+
+
+@pytest.mark.parametrize('name', ['jacobi2d', 'blur', 'heat3d', 'sobel2d',
+                                  'seidel2d', 'denoise2d', 'erosion', 'xcorr',
+                                  'jacobi3d', 'skew2d', 'coupled2d'])
+@pytest.mark.parametrize('iterate', [1, 2, 3])
+def test_valid_boxes_against_brute_force_windows(name, iterate):
+  """Stencil.valid_box (analytic per-dimension bounds, O(iterate)) against the
+  reference's own procedure (ref core.py:876-926): enumerate the overall
+  stencil window of every tensor as a POINT SET -- Minkowski sums of tap sets
+  along the producer chain, iteration after iteration, written here from
+  scratch on plain tuples -- and take its per-dimension extremes (the box of
+  frt/host.py:565-577)."""
+  import re
+  from conftest import soda_path
+  st = core.from_file(soda_path(name + '.soda'), iterate=1)
+  if iterate > 1 and (len(st.input_names) != len(st.output_names) or
+                      st.input_types != st.output_types):
+    pytest.skip('not iterable')
+  st = core.from_file(soda_path(name + '.soda'), iterate=iterate)
+  dim = st.dim
+  zero = (0,) * dim
+  add = lambda a, b: tuple(x + y for x, y in zip(a, b))
+  # window of every tensor relative to the program inputs, by enumeration
+  window = {n: {zero} for n in st.input_names}
+  final = {}
+  for it in range(iterate):
+    for stage in st.ordered_stages:
+      pts = set()
+      for parent, taps in stage.taps.items():
+        for tap in taps:
+          pts |= {add(tap, p) for p in window[parent]}
+      window[stage.name] = pts or {zero}
+    final = dict(window)
+    for i, o in zip(st.input_names, st.output_names):
+      window[i] = window[o]
+  extent = tuple(40 + 7 * d for d in range(dim))
+  for o in st.output_names:
+    pts = final[o]
+    lo = tuple(max(0, -min(p[d] for p in pts)) for d in range(dim))
+    hi = tuple(extent[d] - max(0, max(p[d] for p in pts)) for d in range(dim))
+    assert st.valid_box(extent, o) == (lo, hi), (o, iterate)

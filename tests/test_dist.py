@@ -296,3 +296,17 @@ def test_two_ranks_on_gpu_kernels(tmp_path, name, extent, iterate, every, fuse,
   lo, hi = stencil.valid_box(extent)
   idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
   assert np.array_equal(got[idx], want[idx])
+
+
+def test_thin_slab_is_refused_on_every_rank():
+  """n % world != 0: ranks differ by one row.  The halo check judges the
+  thinnest slab, so either every rank raises or none does (a rank that passed
+  alone would wait forever in the exchange)."""
+  from soda_amd import core, dist as sdist, util
+  st = core.from_file(soda_path('jacobi2d.soda'), iterate=40)
+  # 43 rows over 4 ranks: slabs of 11, 11, 11, 10 rows; halo 10 -> all pass,
+  # halo 11 -> ALL refuse, also the three ranks that own 11 rows
+  for rank in range(4):
+    sdist.Slab(st, (64, 43), 4, rank, 10)
+    with pytest.raises(util.InputError, match='thinner'):
+      sdist.Slab(st, (64, 43), 4, rank, 11)

@@ -49,3 +49,50 @@ def test_generated_host_runs_without_python(built, tmp_path):
                        timeout=300)
   assert run.returncode == 0 and run.stdout.startswith('OK'), (
       run.stdout + run.stderr)
+
+
+def _generate_wire(tmp_path, soda):
+  out = os.path.join(str(tmp_path), 'wire.cpp')
+  subprocess.run([sys.executable, '-m', 'soda_amd.sodac', soda_path(soda),
+                  '--hip-wire-kernel', out], cwd=ROOT, check=True)
+  return out
+
+
+@pytest.mark.parametrize('soda,needle', [
+    # outputs first, then inputs, then the burst count (ref frt/host.py:44-59)
+    ('blur.soda', 'extern "C" void blur_kernel(void* bank_0_blur_y, '
+     'void* bank_0_input, uint64_t coalesced_data_num)'),
+    ('denoise2d.soda', 'extern "C" void denoise2d_kernel(void* bank_0_output, '
+     'void* bank_0_f, void* bank_0_u, uint64_t coalesced_data_num)'),
+    ('heat3d.soda', 'extern "C" void heat3d_kernel(void* bank_0_out, '
+     'void* bank_0_in, uint64_t coalesced_data_num)'),
+])
+def test_generated_wire_kernel_compiles(built, tmp_path, soda, needle):
+  """`sodac --hip-wire-kernel`: the reference kernel's C ABI, defined on
+  libsoda_hip.so's stream object."""
+  src = _generate_wire(tmp_path, soda)
+  text = open(src).read()
+  assert needle in text and 'soda_hip_stream_run_host' in text
+  subprocess.run(['g++', '-std=c++17', '-Wall', '-Werror', '-c', src,
+                  '-I', os.path.join(ROOT, 'include'), '-o',
+                  os.path.join(str(tmp_path), 'wire.o')], check=True)
+
+
+@pytest.mark.gpu
+def test_wire_kernel_links_under_a_reference_style_host(built, tmp_path):
+  """A C++ caller written from the reference host's text (sizes, scatter, the
+  <app>_kernel call with its port order, gather) links against the generated
+  definition and gets the closed-form answer -- no Python in the process."""
+  src = _generate_wire(tmp_path, 'blur.soda')
+  exe = os.path.join(str(tmp_path), 'blur_wire')
+  libdir = os.path.join(ROOT, 'soda_amd')
+  subprocess.run(['g++', '-std=c++17', '-O1', '-DSODA_CPP_BINDING', src,
+                  os.path.join(ROOT, 'tests', 'host', 'blur_wire_main.cpp'),
+                  '-I', os.path.join(ROOT, 'include'), '-L', libdir,
+                  '-lsoda_hip', '-Wl,-rpath,' + libdir, '-o', exe], check=True)
+  env = dict(os.environ)
+  env['LD_LIBRARY_PATH'] = '/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
+  run = subprocess.run([exe], capture_output=True, text=True, env=env,
+                       timeout=300)
+  assert run.returncode == 0 and run.stdout.startswith('OK'), (
+      run.stdout + run.stderr)

@@ -134,3 +134,40 @@ def test_wire_chain_as_dense_view(name, extent):
     want = numpy_oracle.run(st, ins)
     for o in st.output_names:
       assert np.array_equal(got[o], want[o])
+
+
+@pytest.mark.parametrize('name,extent', [('denoise2d.soda', (32, 14)),
+                                         ('coupled2d.soda', (32, 11))])
+def test_wire_chain_with_several_inputs(name, extent):
+  """Programs with more than one input: the reference host delays every input
+  stream by its `produce_offset` (frt/host.py:241-246; the offsets solve the
+  integer program of core.py:371-426, restated in Stencil.produce_offsets).
+  The kernel contract on such streams -- undo the delay, run the causal 1-D
+  program, emit each output late by its stencil offset -- gives the caller the
+  n-D result on the valid box."""
+  from oracle import frt_layout, numpy_oracle
+  st = core.from_file(soda_path(name))
+  delays = st.produce_offsets()
+  assert min(delays.values()) == 0 and set(delays) == set(st.input_names)
+  if name == 'denoise2d.soda':
+    # f is read at (0, 0) only, together with g(0, +-1) = func(u(., +-2)): it
+    # is needed two 32-cell rows later than u
+    assert delays == {'f': 64, 'u': 0}
+  lay = stream.WireLayout(st, extent)
+  rng = np.random.default_rng(8)
+  ins = {n: rng.random(tuple(extent[::-1])).astype(t.np_name)
+         for n, t in zip(st.input_names, st.input_types)}
+  banks = frt_layout.scatter(lay, ins)
+  got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(st.output_names, st.output_types)}
+  frt_layout.gather(lay, frt_layout.kernel_on_streams(lay, banks), got)
+  want = numpy_oracle.run(st, ins)
+  # the host gathers every output over ONE region, that of the program's
+  # stencil window (frt/host.py:357-375): compare there
+  boxes = [st.valid_box(extent, o) for o in st.output_names]
+  lo = [max(b[0][d] for b in boxes) for d in range(st.dim)]
+  hi = [min(b[1][d] for b in boxes) for d in range(st.dim)]
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  for o in st.output_names:
+    assert got[o][idx].any()
+    assert np.array_equal(got[o][idx], want[o][idx])

@@ -37,7 +37,8 @@ def measure(name, extent, iterate, fuse, world=1, reps=5, label=''):
                else torch.randint(0, 30000, shape, device=dev, dtype=dt))
   outs = [torch.empty(shape, device=dev, dtype=TORCH[t.np_name])
           for t in st.output_types]
-  prog = runtime.Program(st, lower.LowerOptions(fuse=fuse), extent=lext)
+  prog = runtime.Program(st, lower.LowerOptions(fuse=fuse), extent=lext,
+                         calibrate=True)
   stream = torch.cuda.current_stream().cuda_stream
 
   def go():
@@ -62,6 +63,8 @@ def measure(name, extent, iterate, fuse, world=1, reps=5, label=''):
              n_gpus=world, local_extent=list(lext), ms=ms, launches=launches,
              exchange_every=every, exchanges=rounds - 1,
              kernels=sorted({k.name for k in prog.module.kernels}),
+             schedule=prog.schedule(lext, every),
+             pass_us={t: round(v, 1) for t, v in prog.pass_times(lext)[0].items()},
              cells_iters_per_s_job=cells * iterate / (ms * 1e-3),
              algorithmic_GBs_per_gpu=local * bpc * launches / (ms * 1e-3) / 1e9
              if all(p.kind != 'direct' for p in prog.module.passes) else None)
@@ -73,14 +76,14 @@ def main():
   out = []
   out.append(measure('blur.soda', (2000, 1024), 1, (), label='C1 blur 2000x1024 (GPU run of the CPU plumbing case)', reps=50))
   out.append(measure('jacobi2d.soda', (8192, 8192), 100, (), label='C2 jacobi2d 8192^2 it=100, one iteration per launch'))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 4), label='C2 jacobi2d 8192^2 it=100, T=12 fused'))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 8, 4), label='C2 jacobi2d 8192^2 it=100, T=12 fused'))
   out.append(measure('blur.soda', (16384, 16384), 1, (), label='C3 blur 16384^2 fused two-stage', reps=20))
   out.append(measure('heat3d.soda', (512, 512, 512), 50, (), label='C4 heat3d 512^3 it=50, one iteration per launch, 1 GPU'))
   out.append(measure('heat3d.soda', (512, 512, 512), 50, (2,), label='C4 heat3d 512^3 it=50, T=2 fused, 1 GPU'))
   out.append(measure('heat3d.soda', (512, 512, 512), 50, (2,), world=8, label='C4 heat3d 512^3 it=50, T=2, slab of an 8-GPU run (compute only, exchanges not timed)'))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 4), label='C5 jacobi2d 8192^2 it=1000, T=12 fused, 1 GPU', reps=2))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 4), world=8, label='C2 jacobi2d 8192^2 it=100, slab of an 8-GPU run (exchange-free)'))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 4), world=8, label='C5 jacobi2d 8192^2 it=1000, slab of an 8-GPU run (compute only, exchanges not timed)', reps=2))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 8, 4), label='C5 jacobi2d 8192^2 it=1000, T=12 fused, 1 GPU', reps=2))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 8, 4), world=8, label='C2 jacobi2d 8192^2 it=100, slab of an 8-GPU run (exchange-free)'))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 8, 4), world=8, label='C5 jacobi2d 8192^2 it=1000, slab of an 8-GPU run (compute only, exchanges not timed)', reps=2))
   out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (4,), label='C5 jacobi2d 8192^2 it=1000, T=4 fused (as BASELINE words it), 1 GPU', reps=2))
   for r in out:
     print(json.dumps(r))
