@@ -177,7 +177,7 @@ size_t soda_hip_last_error(char* buf, size_t cap);
 int soda_hip_device_count(int* count);
 /* sizeof() of the ABI structs as this library was compiled, for bindings to
  * check their mirrors: 0 kargs, 1 kernel_desc, 2 pass_desc, 3 plan,
- * 4 host_tensor; 0 for anything else. */
+ * 4 host_tensor, 5 stream_desc; 0 for anything else. */
 size_t soda_hip_sizeof(int which);
 
 /* -- JIT: HIP source text -> gfx950 code object (hiprtc; needs no GPU) ---- */

@@ -134,6 +134,7 @@ size_t soda_hip_sizeof(int which) {
     case 2: return sizeof(soda_hip_pass_desc_t);
     case 3: return sizeof(soda_hip_plan_t);
     case 4: return sizeof(soda_hip_host_tensor_t);
+    case 5: return sizeof(soda_hip_stream_desc_t);
     default: return 0;
   }
 }

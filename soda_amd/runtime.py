@@ -82,6 +82,20 @@ class Plan(ctypes.Structure):
               ('passes', PassDesc * MAX_PASSES)]
 
 
+class StreamDesc(ctypes.Structure):
+  """Mirror of soda_hip_stream_desc_t (the wire-format kernel, stream.py)."""
+  _fields_ = [('dim', ctypes.c_int32), ('num_inputs', ctypes.c_int32),
+              ('num_outputs', ctypes.c_int32), ('iterate', ctypes.c_int32),
+              ('tile', ctypes.c_int32 * MAX_DIM),
+              ('stencil_distance', ctypes.c_int32),
+              ('banks', ctypes.c_int32 * MAX_TENSORS),
+              ('elem_size', ctypes.c_int32 * MAX_TENSORS),
+              ('elems_per_cycle', ctypes.c_int32 * MAX_TENSORS),
+              ('shift', ctypes.c_int32 * MAX_TENSORS),
+              ('num_linear', ctypes.c_int32),
+              ('linear_vec', ctypes.c_int32 * 4)]
+
+
 class HostTensor(ctypes.Structure):
   _fields_ = [('ptr', ctypes.c_void_p),
               ('extent', ctypes.POINTER(ctypes.c_int32)),
@@ -132,6 +146,16 @@ API = {
     'soda_hip_program_pass_times': (ctypes.c_int, [
         _vp, _pi32, ctypes.POINTER(ctypes.c_float), _pi32
     ]),
+    'soda_hip_stream_create': (ctypes.c_int, [
+        ctypes.POINTER(StreamDesc), _vp, _pvp, _pvp, _pvp, _pvp
+    ]),
+    'soda_hip_stream_destroy': (ctypes.c_int, [_vp]),
+    'soda_hip_stream_run_device': (ctypes.c_int, [
+        _vp, _pvp, _pvp, ctypes.c_uint64, _vp
+    ]),
+    'soda_hip_stream_run_host': (ctypes.c_int, [_vp, _pvp, _pvp,
+                                                ctypes.c_uint64]),
+    'soda_hip_stream_last_mode': (ctypes.c_int, [_vp]),
     'soda_hip_malloc': (ctypes.c_int, [_i32, ctypes.c_size_t, _pvp]),
     'soda_hip_free': (ctypes.c_int, [_i32, _vp]),
     'soda_hip_memcpy_h2d': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
@@ -175,7 +199,7 @@ def library() -> ctypes.CDLL:
       raise util.BackendError('libsoda_hip.so has ABI version %d, expected %d' %
                               (lib.soda_hip_abi_version(), ABI_VERSION))
     for which, mirror in ((1, KernelDesc), (2, PassDesc), (3, Plan),
-                          (4, HostTensor)):
+                          (4, HostTensor), (5, StreamDesc)):
       if lib.soda_hip_sizeof(which) != ctypes.sizeof(mirror):
         raise util.BackendError(
             'struct layout mismatch between libsoda_hip.so and runtime.py '

@@ -135,18 +135,7 @@ extern "C" __global__ void __launch_bounds__(256) %(name)s(soda_hip_kargs_t a) {
 }
 """
 
-# the library's mirror of soda_hip_stream_desc_t
-class StreamDesc(ctypes.Structure):
-  _fields_ = [('dim', ctypes.c_int32), ('num_inputs', ctypes.c_int32),
-              ('num_outputs', ctypes.c_int32), ('iterate', ctypes.c_int32),
-              ('tile', ctypes.c_int32 * runtime.MAX_DIM),
-              ('stencil_distance', ctypes.c_int32),
-              ('banks', ctypes.c_int32 * runtime.MAX_TENSORS),
-              ('elem_size', ctypes.c_int32 * runtime.MAX_TENSORS),
-              ('elems_per_cycle', ctypes.c_int32 * runtime.MAX_TENSORS),
-              ('shift', ctypes.c_int32 * runtime.MAX_TENSORS),
-              ('num_linear', ctypes.c_int32),
-              ('linear_vec', ctypes.c_int32 * 4)]
+StreamDesc = runtime.StreamDesc
 
 
 class ProgramSpec:
@@ -309,17 +298,6 @@ class StreamProgram:
                   for s in stencil.input_stmts + stencil.output_stmts}
     self.stencil_offset = stencil_offsets(stencil)   # a program constant
     self._lib = lib = runtime.library()
-    lib.soda_hip_stream_create.restype = ctypes.c_int
-    lib.soda_hip_stream_run_device.restype = ctypes.c_int
-    lib.soda_hip_stream_run_device.argtypes = [
-        ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
-        ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_void_p]
-    lib.soda_hip_stream_run_host.restype = ctypes.c_int
-    lib.soda_hip_stream_run_host.argtypes = [
-        ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
-        ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64]
-    lib.soda_hip_stream_last_mode.argtypes = [ctypes.c_void_p]
-    lib.soda_hip_stream_destroy.argtypes = [ctypes.c_void_p]
     self._programs: Dict[str, ctypes.c_void_p] = {}
     codes = {}
     for tag, spec in self.specs.items():
