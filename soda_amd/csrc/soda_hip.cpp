@@ -783,36 +783,39 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipMemsetAsync");
   }
   std::vector<double> ns(plan.num_passes, 0.0);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (rc == SODA_HIP_OK && (hipEventCreate(&e0) != hipSuccess ||
-                            hipEventCreate(&e1) != hipSuccess))
-    rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventCreate");
+  // one event pair per pass, recorded in the LAST of four rounds over all the
+  // passes; nothing synchronises in between, so the GPU never idles and the
+  // timed round runs at the clocks a long run holds (a burst of launches a
+  // millisecond after idle reads 20-30 % slow, and not equally per pass)
+  std::vector<hipEvent_t> ev(2 * plan.num_passes, nullptr);
+  for (auto& e : ev)
+    if (rc == SODA_HIP_OK && hipEventCreate(&e) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventCreate");
   if (rc == SODA_HIP_OK) {
     for (int i = 0; i < plan.num_inputs; ++i) ins.push_back(bufs[i].ptr);
     for (int k = 0; k < plan.num_params; ++k)
       ins.push_back(bufs[plan.num_inputs + plan.num_outputs + k].ptr);
     for (int o = 0; o < plan.num_outputs; ++o)
       outs.push_back(bufs[plan.num_inputs + o].ptr);
-    // four rounds over all passes; the first two bring the clocks to where a
-    // long run holds them (a launch a millisecond after idle reads 20-30 %
-    // slow, and not equally for every pass), the faster of the last two counts
     for (int round = 0; round < 4 && rc == SODA_HIP_OK; ++round)
       for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
         const int32_t iters = plan.passes[i].fused_iters * launches;
-        (void)hipEventRecord(e0, stream);
+        if (round == 3) (void)hipEventRecord(ev[2 * i], stream);
         rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
                       iters, stream_, i);
-        (void)hipEventRecord(e1, stream);
-        if (rc == SODA_HIP_OK && hipEventSynchronize(e1) != hipSuccess)
-          rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventSynchronize");
-        float ms = 0;
-        if (rc == SODA_HIP_OK) (void)hipEventElapsedTime(&ms, e0, e1);
-        const double t = ms * 1e6 / launches;
-        if (round == 2 || (round == 3 && t < ns[i])) ns[i] = t;
+        if (round == 3) (void)hipEventRecord(ev[2 * i + 1], stream);
       }
+    if (rc == SODA_HIP_OK && hipStreamSynchronize(stream) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipStreamSynchronize");
+    for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess)
+        rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventElapsedTime");
+      ns[i] = ms * 1e6 / launches;
+    }
   }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& b : bufs)
     if (b.ptr) (void)hipFree(b.ptr);
   if (rc == SODA_HIP_OK) p->measured[key] = ns;

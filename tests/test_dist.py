@@ -310,3 +310,49 @@ def test_thin_slab_is_refused_on_every_rank():
     sdist.Slab(st, (64, 43), 4, rank, 10)
     with pytest.raises(util.InputError, match='thinner'):
       sdist.Slab(st, (64, 43), 4, rank, 11)
+
+
+def _run_bench(*flags, timeout=600):
+  import subprocess
+  import sys
+  env = dict(os.environ)
+  env.pop('WORLD_SIZE', None)
+  env.pop('RANK', None)
+  return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *flags],
+                        capture_output=True, text=True, env=env,
+                        timeout=timeout)
+
+
+def test_bench_launcher_refuses_without_enough_gpus():
+  """`bench.py --gpus N` started by hand is its own launcher; on a box with
+  fewer than N GPUs (this one has none) it says so and exits non-zero at once,
+  having launched nothing -- no hang, no traceback."""
+  import torch
+  if torch.cuda.device_count() >= 2:
+    pytest.skip('this box could run it')
+  run = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', timeout=120)
+  assert run.returncode == 2
+  assert 'needs 2 GPUs' in run.stderr and 'nothing was launched' in run.stderr
+  assert 'Traceback' not in run.stderr and not run.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_launcher_on_the_gpu_box():
+  """On the GPU box: with two or more GPUs the self-launched 2-rank run must
+  come back with one JSON line from rank 0 and `rccl_world` = 2 (the RCCL
+  process group really formed); with one GPU the launcher must refuse cleanly."""
+  import json
+  import torch
+  if torch.cuda.device_count() >= 2:
+    run = _run_bench('--gpus', '2', '--steps', '2', '--warmup', '1',
+                     '--no-cpu-baseline', '--no-single-iter')
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['rccl_world'] == 2
+    assert out['config']['exchanges_per_step'] >= 1
+  else:
+    run = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0',
+                     timeout=300)
+    assert run.returncode == 2 and 'needs 2 GPUs' in run.stderr
+    assert not run.stdout.strip()

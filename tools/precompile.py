@@ -27,6 +27,7 @@ def main():
   ap.add_argument('--cw', type=int, nargs='+', default=[0])
   ap.add_argument('--peel', type=int, nargs='+', default=[-2])
   ap.add_argument('--mw', type=int, nargs='+', default=[0])
+  ap.add_argument('--reg-budget', type=int, default=None)
   ap.add_argument('--launches', type=int, default=1)
   args = ap.parse_args()
   from soda_amd import core, runtime
@@ -42,7 +43,7 @@ def main():
                               nt_store=bool(nts), xcd_swizzle=True,
                               tile_rows=trows, waves_x=1, waves_y=1,
                               counted_waits=bool(cw), peel=(None if peel == -2 else peel),
-                              min_waves=mw)
+                              min_waves=mw, reg_budget=args.reg_budget)
     try:
       opts = runtime.resolve_options(st, opts, args.extent)
       mod = lower.lower(st, opts)
