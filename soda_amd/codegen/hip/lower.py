@@ -77,8 +77,14 @@ class LowerOptions:
                pipe: Optional[int] = None, pipe_rows: int = 2,
                reg_budget: Optional[int] = None,
                counted_waits: Optional[bool] = None, stamps: bool = False,
-               peel=None):
+               peel=None, align_lanes: Optional[int] = None):
     self.stamps = stamps
+    # valid lanes of a strip as a multiple of this; None: as many as make a
+    # strip's output rows start on 64-byte boundaries where they are written
+    # with non-temporal stores, else 1
+    if align_lanes is None and os.environ.get('SODA_HIP_ALIGN_LANES'):
+      align_lanes = int(os.environ['SODA_HIP_ALIGN_LANES'])   # A/B runs
+    self.align_lanes = align_lanes
     # trips of the unrolled loop whose warm-up is peeled into straight-line
     # code without the stages that do not matter yet: an int for every fusion
     # depth, a dict {depth: trips}, -1 = all of the warm-up, None = let
@@ -129,7 +135,7 @@ class LowerOptions:
                        self.interleave, self.lane_shift, self.min_waves,
                        self.occupancy, self.buffer_ops, self.pipe,
                        self.pipe_rows, self.reg_budget, self.counted_waits,
-                       self.stamps, self.peel)
+                       self.stamps, self.peel, self.align_lanes)
     if out.prefetch is None and dim == 3:
       out.prefetch = 1
     # 2-D: resolved per fusion depth in lower() (default_prefetch)
@@ -229,6 +235,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
             opts.waves_x * opts.waves_y == 1)
       return want if ok else 1
 
+    out_bytes = min(t.size_in_bytes for t in stencil.output_types)
+
     def config(t: int, vec: int, pf: int, rows: Optional[int] = None
                ) -> MarchConfig:
       cfg = MarchConfig(t, vec, opts.chunk_rows or 64, pf,
@@ -239,7 +247,10 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
                         opts.lane_shift, opts.min_waves, opts.occupancy,
                         opts.buffer_ops,
                         pipe_for(t), opts.pipe_rows, opts.counted_waits,
-                        opts.stamps, peel_for(t))
+                        opts.stamps, peel_for(t),
+                        opts.align_lanes if opts.align_lanes is not None else
+                        (max(1, 64 // (vec * out_bytes)) if opts.nt_store
+                         else 1))
       cfg.chunk_fixed = opts.chunk_rows is not None
       return cfg
 

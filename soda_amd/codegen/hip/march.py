@@ -92,7 +92,14 @@ class MarchConfig:
                min_waves: int = 0, occupancy: int = 0,
                buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4,
                counted_waits: bool = False, stamps: bool = False,
-               peel: int = -1):
+               peel: int = -1, align_lanes: int = 1):
+    # valid lanes of a strip rounded down to a multiple of this (extra halo
+    # lanes on the high side): 4 makes a strip's rows start and end on 64-byte
+    # boundaries.  Pays where rows are written with non-temporal stores -- a
+    # 63-lane strip's 1008-byte rows end in partial lines that go to memory
+    # twice (blur 16384^2: 225 -> 202 us at 60 lanes) -- and not with plain
+    # stores, which L2 merges (jacobi2d T = 4 / 8 / 12: no gain, slower)
+    self.align_lanes = max(1, int(align_lanes))
     # the pipeline warm-up of a chunk as straight-line code in front of the
     # loop, WITHOUT the stages whose rows cannot reach an output row of the
     # chunk yet (fused iteration l first matters 2l row steps into the chunk:
@@ -180,7 +187,9 @@ class MarchConfig:
                                     if self.pipe > 1 else '') + (
                                         '_st' if self.stamps else '') + (
                                             '' if self.peel < 0 else
-                                            '_k%d' % self.peel)
+                                            '_k%d' % self.peel) + (
+                                                '_al%d' % self.align_lanes
+                                                if self.align_lanes > 1 else '')
 
 
 March2DConfig = MarchConfig   # older name
@@ -363,6 +372,10 @@ class _MarchKernel:
         self.nodes, self.inputs, self.outputs = _build_chain(
             self.st, self.T, self.PF, self.edge, self.W, self.R)
         self.out_nodes = list(self.outputs.values())
+    if self.cfg.align_lanes > 1 and self.group == 64:
+      spare = (64 - self.lanes_lo - self.lanes_hi) % self.cfg.align_lanes
+      if self.lanes_lo + self.lanes_hi + spare < 16:
+        self.lanes_hi += spare
     if self.lanes_lo + self.lanes_hi >= self.group // 2:
       raise util.SemanticError('march: halo of %d+%d cells is too wide for a '
                                '%d-lane strip at %d cells per lane' %

@@ -9,7 +9,7 @@ import torch
 from soda_amd import runtime, streamcopy
 
 def main():
-  n = 8192 * 8192
+  n = 8192 * 8192 * (int(sys.argv[1]) if len(sys.argv) > 1 else 1)   # floats per array
   dev = torch.device('cuda', 0)
   bufs = [torch.rand(n, device=dev) for _ in range(3)]
   stream = torch.cuda.current_stream().cuda_stream
