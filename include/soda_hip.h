@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 4
+#define SODA_HIP_ABI_VERSION 5
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
 #define SODA_HIP_MAX_KERNELS 32
@@ -126,6 +126,10 @@ typedef struct soda_hip_kernel_desc {
   float bytes_per_cell;                /* HBM bytes per cell per launch (inputs
                                           + outputs), before halo re-reads */
   float lane_redundancy;               /* lanes of a strip / lanes that store */
+  int32_t max_extent0;                 /* > 0: the kernel's block covers the
+                                          whole row (its waves hand x-halos
+                                          over through LDS): extent[0] must not
+                                          exceed this, else ERR_INVALID */
 } soda_hip_kernel_desc_t;
 
 /* One way of advancing the program by `fused_iters` iterations: the listed

@@ -58,7 +58,8 @@ def emit_plan(w, func: str, plan) -> None:
     for k in range(4):
       w('  plan.kernels[%d].tile[%d] = %d;' % (i, k, max(1, d.tile[k])))
     for field in ('lds_bytes', 'vec', 'march_dim', 'waves_along', 'warm',
-                  'window_extra', 'max_elem', 'vgprs', 'pipe', 'chunk_fixed'):
+                  'window_extra', 'max_elem', 'vgprs', 'pipe', 'chunk_fixed',
+                  'max_extent0'):
       w('  plan.kernels[%d].%s = %d;' % (i, field, getattr(d, field)))
     for field in ('step_ns', 'warm_saved', 'bytes_per_cell',
                   'lane_redundancy'):

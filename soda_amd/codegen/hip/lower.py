@@ -77,8 +77,20 @@ class LowerOptions:
                pipe: Optional[int] = None, pipe_rows: int = 2,
                reg_budget: Optional[int] = None,
                counted_waits: Optional[bool] = None, stamps: bool = False,
-               peel=None, align_lanes: Optional[int] = None):
+               peel=None, align_lanes: Optional[int] = None,
+               xshare: Optional[bool] = None,
+               row_cells: Optional[int] = None):
     self.stamps = stamps
+    # fused 3-D kernels whose block covers the whole row, x-halos handed over
+    # through LDS (MarchConfig.xshare).  Needs the row length the program will
+    # run on (`row_cells` = extent[0]; runtime.Program fills it in from its
+    # extent): the kernels then REFUSE any other row length at launch.
+    # None: where it applies (3-D, fused, <= 4 waves per row); True also in
+    # 2-D; SODA_HIP_XSHARE=0/1 overrides for A/B runs
+    if xshare is None and os.environ.get('SODA_HIP_XSHARE'):
+      xshare = os.environ['SODA_HIP_XSHARE'] == '1'
+    self.xshare = xshare
+    self.row_cells = row_cells
     # valid lanes of a strip as a multiple of this; None: as many as make a
     # strip's output rows start on 64-byte boundaries where they are written
     # with non-temporal stores, else 1
@@ -135,7 +147,8 @@ class LowerOptions:
                        self.interleave, self.lane_shift, self.min_waves,
                        self.occupancy, self.buffer_ops, self.pipe,
                        self.pipe_rows, self.reg_budget, self.counted_waits,
-                       self.stamps, self.peel, self.align_lanes)
+                       self.stamps, self.peel, self.align_lanes, self.xshare,
+                       self.row_cells)
     if out.prefetch is None and dim == 3:
       out.prefetch = 1
     # 2-D: resolved per fusion depth in lower() (default_prefetch)
@@ -237,8 +250,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
 
     out_bytes = min(t.size_in_bytes for t in stencil.output_types)
 
-    def config(t: int, vec: int, pf: int, rows: Optional[int] = None
-               ) -> MarchConfig:
+    def config(t: int, vec: int, pf: int, rows: Optional[int] = None,
+               xshare: int = 0) -> MarchConfig:
       cfg = MarchConfig(t, vec, opts.chunk_rows or 64, pf,
                         opts.waves_x, opts.waves_y, opts.nt_store,
                         opts.nt_load, opts.xcd_swizzle, opts.edge_loads,
@@ -250,7 +263,7 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
                         opts.stamps, peel_for(t),
                         opts.align_lanes if opts.align_lanes is not None else
                         (max(1, 64 // (vec * out_bytes)) if opts.nt_store
-                         else 1))
+                         else 1), xshare)
       cfg.chunk_fixed = opts.chunk_rows is not None
       return cfg
 
@@ -298,14 +311,26 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
       use_march = False
     else:
       _, vec, pf1, rows1 = chosen
+      # waves that cover a whole row side by side, sharing x-halos through LDS
+      share = 0
+      if opts.row_cells and opts.xshare is not False and \
+          (stencil.dim == 3 or opts.xshare) and opts.pipe in (None, 1):
+        share = -(-opts.row_cells // (64 * vec))
+        if share > (4 if opts.xshare is None else 16):
+          share = 0
       for t in depths:
         keep = (len(mod.kernels), len(mod.passes), len(mod.chunks))
-        try:
-          add_march_pass(mod, config(t, vec,
-                                     opts.prefetch or default_prefetch(t)))
-        except util.SemanticError:
-          # this depth does not fit; the scheduler uses the others
-          del mod.kernels[keep[0]:], mod.passes[keep[1]:], mod.chunks[keep[2]:]
+        for xs in ([share, 0] if share and t > 1 else [0]):
+          try:
+            add_march_pass(mod, config(t, vec,
+                                       opts.prefetch or default_prefetch(t),
+                                       xshare=xs))
+            break
+          except util.SemanticError:
+            # this shape does not fit: try without sharing; if the depth does
+            # not fit at all the scheduler uses the others
+            del mod.kernels[keep[0]:], mod.passes[keep[1]:], \
+                mod.chunks[keep[2]:]
       add_march_pass(mod, config(1, vec, pf1, rows1))
   if not use_march:
     add_direct_pass(mod, opts.vec or 1)

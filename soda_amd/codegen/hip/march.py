@@ -41,6 +41,9 @@ class _Node:
     # on cells one iteration cannot compute (it is then also a parent, tapped
     # at offset 0)
     self.keep: Optional[str] = None
+    # x-halo sharing: the strip's neighbours hand this tensor's end cells over
+    # through LDS (one register per row slot holds them, like edge loads)
+    self.xs = False
 
   def tap_bounds(self, pname: str):
     """Bounds of the taps on parent `pname`, the offset-0 tap of a preserved
@@ -92,7 +95,17 @@ class MarchConfig:
                min_waves: int = 0, occupancy: int = 0,
                buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4,
                counted_waits: bool = False, stamps: bool = False,
-               peel: int = -1, align_lanes: int = 1):
+               peel: int = -1, align_lanes: int = 1, xshare: int = 0):
+    # x-halos shared through LDS: a block of `xshare` waves covers the WHOLE
+    # row (extent[0] <= xshare * 64 * vec, checked at launch), every wave a
+    # strip of 64 fully valid lanes; the one cell a fused iteration needs from
+    # the neighbouring strip's intermediate results is handed over through LDS
+    # (lanes 0 and 63 write their end cells, one barrier per row step, the
+    # neighbour reads them into the register DPP shifts take their `old`
+    # operand from -- the mechanism edge loads use for the program inputs).
+    # Without it a T = 2 strip of heat3d has 62 valid lanes = 248 cells and a
+    # 512-cell row needs THREE waves, the third nearly idle.
+    self.xshare = int(xshare)
     # valid lanes of a strip rounded down to a multiple of this (extra halo
     # lanes on the high side): 4 makes a strip's rows start and end on 64-byte
     # boundaries.  Pays where rows are written with non-temporal stores -- a
@@ -189,7 +202,9 @@ class MarchConfig:
                                             '' if self.peel < 0 else
                                             '_k%d' % self.peel) + (
                                                 '_al%d' % self.align_lanes
-                                                if self.align_lanes > 1 else '')
+                                                if self.align_lanes > 1 else '') + (
+                                                    '_xs%d' % self.xshare
+                                                    if self.xshare else '')
 
 
 March2DConfig = MarchConfig   # older name
@@ -212,7 +227,7 @@ march2d_supported = march_supported
 
 
 def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
-                 pipe: int = 1, pipe_rows: int = 1):
+                 pipe: int = 1, pipe_rows: int = 1, xshare: bool = False):
   """The tensors of T chained iterations with their schedule (delay in ticks
   behind the load of the input plane, window of planes kept, invalid margins).
   `pipe` > 1 splits the iterations evenly over that many waves of a block:
@@ -256,6 +271,38 @@ def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
     last_outputs = {o: env[o] for o in st.output_names}
     if it < T - 1:
       cur_inputs = {i: env[o] for i, o in zip(st.input_names, st.output_names)}
+  def share(n: _Node) -> None:
+    """x-halo sharing: if some consumer taps `n` off-centre along dim 0, the
+    neighbouring strips hand its end cells over (one valid cell per side)."""
+    reach = 0
+    for c in nodes:
+      if c.stage is None or c.mirror_of is not None:
+        continue
+      for pname, p in c.parents.items():
+        if p is not n:
+          continue
+        tlo, thi = c.tap_bounds(pname)
+        reach = max(reach, -tlo[0], thi[0])
+        if tlo[0] < 0 or thi[0] > 0:
+          # the halo cells of a plane arrive at the END of the row step that
+          # computes it (or first reads it, for an input): taps off-centre in
+          # x must not touch the newest plane the consumer reads
+          newest = max(off[ax] for off in c.stage.taps.get(pname, ())
+                       if off[0] != 0)
+          if newest >= thi[ax]:
+            raise util.SemanticError(
+                'march: x-halo sharing needs a row step between a plane and '
+                'its off-centre taps (%s reads %s)' % (c.var, n.var))
+    if reach:
+      if reach > 1 or n.margin[0] > 0 or n.margin[1] > 0:
+        raise util.SemanticError(
+            'march: x-halo sharing hands over one valid cell per side')
+      n.xs = True
+      n.margin = [n.margin[0] - 1, n.margin[1] - 1]
+
+  if xshare:
+    for n in inputs.values():
+      share(n)
   # delays and margins, in chain order
   for n in nodes:
     if n.mirror_of is not None:
@@ -283,6 +330,8 @@ def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
     n.delay = delay if delay is not None else 0
     n.margin = margin
     n.rmargin = rmargin
+    if xshare:
+      share(n)
   # windows: a parent keeps planes from its newest (age 0) to the oldest any
   # child still reads
   for n in nodes:
@@ -355,14 +404,26 @@ class _MarchKernel:
     self.R = self.cfg.pipe_rows if self.W > 1 else 1
     if self.R & (self.R - 1):
       raise util.SemanticError('march: rows per barrier must be a power of two')
+    self.xs = self.cfg.xshare
+    if self.xs:
+      self.edge = (0, 0)    # the inputs' halo cells travel through LDS as well
+      if self.W > 1 or self.cfg.lane_shift != 'dpp' or not self.cfg.buffer_ops \
+          or self.cfg.counted_waits or self.cfg.waves_x * self.cfg.waves_y != 1:
+        raise util.SemanticError(
+            'march: x-halo sharing needs DPP shifts, buffer addressing and '
+            'one wave per strip')
+      if not 1 <= self.xs <= 16:
+        raise util.SemanticError('march: 1 to 16 waves can share a row')
+      if self.dim == 3 and self.cfg.tile_rows > 24:
+        raise util.SemanticError('march: x-halo sharing holds a row per lane')
     self.nodes, self.inputs, self.outputs = _build_chain(
-        self.st, self.T, self.PF, self.edge, self.W, self.R)
+        self.st, self.T, self.PF, self.edge, self.W, self.R, bool(self.xs))
     self.out_nodes = list(self.outputs.values())
     self.margin_lo = max(0, max(n.margin[0] for n in self.out_nodes))
     self.margin_hi = max(0, max(n.margin[1] for n in self.out_nodes))
     self.lanes_lo = -(-self.margin_lo // self.V)
     self.lanes_hi = -(-self.margin_hi // self.V)
-    if self.edge != (0, 0):
+    if self.edge != (0, 0) and not self.xs:
       # edge loads only pay when they save a halo lane
       plain = _build_chain(self.st, self.T, self.PF, (0, 0), self.W, self.R)[2]
       p_lo = -(-max(n.margin[0] for n in plain.values()) // self.V)
@@ -370,7 +431,7 @@ class _MarchKernel:
       if (p_lo, p_hi) == (self.lanes_lo, self.lanes_hi):
         self.edge = (0, 0)
         self.nodes, self.inputs, self.outputs = _build_chain(
-            self.st, self.T, self.PF, self.edge, self.W, self.R)
+            self.st, self.T, self.PF, self.edge, self.W, self.R, bool(self.xs))
         self.out_nodes = list(self.outputs.values())
     if self.cfg.align_lanes > 1 and self.group == 64:
       spare = (64 - self.lanes_lo - self.lanes_hi) % self.cfg.align_lanes
@@ -501,6 +562,8 @@ class _MarchKernel:
     self.wx = self.cfg.waves_x if self.dim == 2 else 1
     if self.W > 1:
       self.waves = self.W
+    if self.xs:
+      self.waves = self.xs
     self.block = 64 * self.waves
     self.L: List[str] = []
     self.w = self.L.append
@@ -610,7 +673,10 @@ class _MarchKernel:
     self.w('  const int tile_x = (int)(bid % (unsigned)a.ntile[0]);')
     if self.dim == 2:
       self.w('  const int tile_m = (int)(bid / (unsigned)a.ntile[0]);')
-      if self.W > 1:        # all waves of the block share the strip and the chunk
+      if self.xs:           # the block's waves cover the row side by side
+        self.w('  const int strip = wave;')
+        self.w('  const int chunk = tile_m;')
+      elif self.W > 1:      # all waves of the block share the strip and the chunk
         self.w('  const int strip = tile_x;')
         self.w('  const int chunk = tile_m;')
       else:
@@ -622,7 +688,7 @@ class _MarchKernel:
         '(unsigned)a.ntile[1]);')
       self.w('  const int chunk = (int)(bid / ((unsigned)a.ntile[0] * '
         '(unsigned)a.ntile[1]));')
-      self.w('  const int strip = tile_x;')
+      self.w('  const int strip = %s;' % ('wave' if self.xs else 'tile_x'))
       self.w('  const int n0 = a.extent[0], n1 = a.extent[1], nm = a.extent[2];')
       self.w('  const int y0 = tile_y * %d - %d;  // first row held' %
         (self.tile_rows, self.rhalo_lo))
@@ -641,8 +707,12 @@ class _MarchKernel:
       (self.ax, self.cfg.waves_y if self.dim == 2 else 1))
     self.w('  const int m_begin = chunk * chunk_len;')
     self.w('  const int m_end = min(m_begin + chunk_len, nm);')
-    self.w('  if (m_begin >= nm || strip * %d >= n0) return;  // wave-uniform' %
-      self.strip_cells)
+    if self.xs:
+      # every wave of the block takes part in the barriers, whatever its strip
+      self.w('  if (m_begin >= nm) return;  // block-uniform')
+    else:
+      self.w('  if (m_begin >= nm || strip * %d >= n0) return;  // wave-uniform' %
+        self.strip_cells)
     self.w('  const bool lane_ok = x0 >= 0 && x0 + %d <= n0;' % self.V)
     self.w('  const bool store_ok = lane_ok && sub >= %d && sub < %d;' %
       (self.lanes_lo, self.group - self.lanes_hi))
@@ -684,10 +754,37 @@ class _MarchKernel:
       for o, n in self.outputs.items():
         self.w('  %s* __restrict__ q_%s = (%s*)a.buf[%d] + x0c;' %
           (n.ctype, o, n.ctype, self.mod.slot[o]))
+    if self.xs or self.n_edge:
+      self.w('  const bool edge_lane = lane == 0 || lane == 63;')
+    self.xs_nodes = [n for n in self.nodes if n.xs]
+    if self.xs_nodes:    # (none: no tap leaves its column, nothing to share)
+      self.xs_rows = max(len(self.rows_of(n)) for n in self.xs_nodes)
+      if self.xs_rows > 32:
+        raise util.SemanticError('march: x-halo sharing holds a row per lane')
+      self.xs_stride = self.xs * 2 * self.xs_rows
+      for n in self.xs_nodes:
+        # [parity of the row step][wave][0: its first cell, 1: its last][row],
+        # then one cell that stays zero (what lies beyond the row's ends)
+        self.w('  __shared__ %s soda_xs_%s[%d];' %
+               (n.ctype, n.var, 2 * self.xs_stride + 1))
+      self.w('  if (threadIdx.x == 0) {')
+      for n in self.xs_nodes:
+        self.w('    soda_xs_%s[%d] = (%s)0;' % (n.var, 2 * self.xs_stride, n.ctype))
+      self.w('  }')
+      self.w('  soda_pipe_barrier();')
+      # writing: lane 0 files its first cell, lane 63 its last
+      self.w('  const int xs_wr = (wave * 2 + (lane == 0 ? 0 : 1)) * %d;' %
+             self.xs_rows)
+      # reading: lane r takes row r's cell from the strip on the left (its last
+      # cell), lane 32 + r from the strip on the right (its first cell); lanes
+      # without a neighbour or a row read the zero cell
+      self.w('  const int xs_nb = lane < 32 ? wave - 1 : wave + 1;')
+      self.w('  const int xs_rd = (xs_nb >= 0 && xs_nb < %d && (lane & 31) < %d) ? '
+             '(xs_nb * 2 + (lane < 32 ? 1 : 0)) * %d + (lane & 31) : %d;' %
+             (self.xs, self.xs_rows, self.xs_rows, 2 * self.xs_stride))
     if self.n_edge:
       # lane 0 fetches the cells left of the strip, lane 63 those right of it;
       # DPP hands them to the shifted reads through the `old` operand
-      self.w('  const bool edge_lane = lane == 0 || lane == 63;')
       for i in range(self.n_edge):
         self.w('  const int ex%d = lane == 0 ? x0 - %d : x0 + %d;' %
           (i, 1 + i, self.V + i))
@@ -746,6 +843,10 @@ class _MarchKernel:
             if n.is_input and self.cw:
               for var, nb, _, _ in self.raw_groups(n, s, j):
                 self.w('  %s %s = {};' % (self._RAW_TYPE[nb], var))
+          if n.xs:
+            # halo cells of the plane in slot s: lane r / 32 + r holds row r's
+            # left / right neighbour cell
+            self.w('  %s hv_%s_s%d = (%s)0;' % (n.ctype, n.var, s, n.ctype))
 
   def emit_loads(self, k: int, t_expr: str, pin: bool = False) -> None:
       """Issues the loads of input plane t (tick phase k).  `pin`: the step is
@@ -931,6 +1032,23 @@ class _MarchKernel:
     # 2. compute every tensor's new plane
     self._shifted: Dict[Tuple[str, int, int, int, int], str] = {}
     self._stage_mark = len(self.L)
+    # (tensor, slot) whose end cells change hands at the end of this step: the
+    # planes computed in it, and the input plane whose load it is first to use
+    fresh_xs: List[Tuple[_Node, int]] = []
+    if self.xs and wv == 0:
+      for n in self.inputs.values():
+        if n.xs:
+          fresh_xs.append((n, self.slot_of(n, k, self.PF)))
+      # the neighbours' end cells of the planes handed over at the end of the
+      # previous step: one LDS read per tensor, row r in lanes r and 32 + r
+      # (stale or unwritten values reach only planes no output depends on)
+      for n in self.nodes:
+        if not n.xs:
+          continue
+        slot = self.slot_of(n, k - 1, self.PF if n.is_input else 0)
+        self.w('      hv_%s_s%d = soda_xs_%s[xs_rd < %d ? xs_rd + ((t - 1) & 1) * %d '
+               ': xs_rd];' % (n.var, slot, n.var, 2 * self.xs_stride,
+                              self.xs_stride))
     for n in self.nodes:
       if n.stage is not None and n.owner == wv:
         if step is not None and not self.stage_needed(n, step):
@@ -938,7 +1056,21 @@ class _MarchKernel:
             self._emit_dummy_stores(wv, only=n, salt=step + 1)
           continue
         self._emit_stage(n, k)
+        if n.xs:
+          fresh_xs.append((n, self.slot_of(n, k, 0)))
     self.shift_temps = max(self.shift_temps, len(self._shifted))
+    if fresh_xs:
+      # x-halo hand-over of the planes computed (first read, for an input) in
+      # this step: lanes 0 and 63 put their end cells into LDS; the barrier
+      # also keeps the next write of this parity behind every wave's reads
+      self.w('      if (edge_lane) {')
+      for n, slot in fresh_xs:
+        for jj, j in enumerate(self.rows_of(n)):
+          reg = '%s_s%d_r%d' % (n.var, slot, j)
+          self.w('        soda_xs_%s[xs_wr + (t & 1) * %d + %d] = lane == 0 ? %s[0] '
+                 ': %s[%d];' % (n.var, self.xs_stride, jj, reg, reg, self.V - 1))
+      self.w('      }')
+      self.w('      soda_pipe_barrier();')
     self.w('    }')
 
   def _emit_stage(self, n: _Node, k: int) -> None:
@@ -976,12 +1108,19 @@ class _MarchKernel:
       if key not in self._shifted:
         tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',
                                   abs(lane_off))
-        if p.is_input and self.n_edge:
+        if (p.is_input and self.n_edge) or p.xs:
           if abs(lane_off) != 1:
             raise util.InternalError('march: edge loads reach one lane')
           # cell index relative to the strip end, served by the edge lane
           ei = (-c - 1) if lane_off < 0 else (c - self.V)
-          old = '%s_e[%d]' % (reg, ei) if 0 <= ei < self.n_edge else '(%s)0' % p.ctype
+          if p.xs:
+            # broadcast from the halo vector of the plane (a scalar register)
+            rr = row - p.rmargin[0] + (0 if lane_off < 0 else 32)
+            old = ('soda_bcast(hv_%s_s%d, %d)' % (p.var, slot, rr)
+                   if ei == 0 else '(%s)0' % p.ctype)
+          else:
+            old = '%s_e[%d]' % (reg, ei) if 0 <= ei < self.n_edge else \
+                '(%s)0' % p.ctype
           expr = ('soda_lane_dn_or(%s, %s)' if lane_off < 0 else
                   'soda_lane_up_or(%s, %s)') % (src, old)
         elif self.use_bperm:
@@ -1003,7 +1142,8 @@ class _MarchKernel:
         # a shift of a row produced in an EARLIER tick can be issued ahead
         # of the previous stage's arithmetic (latency hidden behind it)
         early = (self.use_bperm or self.use_swz) and (
-            p.is_input or age > 0) and not (p.is_input and self.n_edge)
+            p.is_input or age > 0) and not (p.is_input and self.n_edge) \
+            and not p.xs
         (_early if early else _pre).append(line)
         self._shifted[key] = tmp
       return self._shifted[key]
@@ -1169,9 +1309,11 @@ class _MarchKernel:
     saved = sum(1 for i in range(self.peeled) for n in stages
                 if not self.stage_needed(n, i)) / float(max(1, len(stages)))
     if self.dim == 2:
-      tile = (self.strip_cells * self.wx, self.cfg.chunk_rows * self.cfg.waves_y)
+      tile = (self.strip_cells * (self.xs or self.wx),
+              self.cfg.chunk_rows * self.cfg.waves_y)
     else:
-      tile = (self.strip_cells, self.tile_rows, self.cfg.chunk_rows)
+      tile = (self.strip_cells * (self.xs or 1), self.tile_rows,
+              self.cfg.chunk_rows)
     lds_pad = 0
     if self.cfg.occupancy:
       blocks_per_cu = max(1, 4 * self.cfg.occupancy // self.waves)
@@ -1191,7 +1333,8 @@ class _MarchKernel:
                              peel_trips_max=self.peel_trips_max,
                              fused=self.T,
                              window_extra=(self.m_hi - self.m_lo) if self.buf else None,
-                             max_elem=max(self.esz.values()))),
+                             max_elem=max(self.esz.values()),
+                             max_extent0=self.strip_cells * self.xs)),
         '\n'.join(self.L) + '\n')
     table = self.st.symbol_table
     bytes_in = sum(table[i].size_in_bytes for i in self.st.input_names)

@@ -335,6 +335,9 @@ int waves_per_simd(int vgprs) {
   return w < 1 ? 1 : w > 8 ? 8 : w;
 }
 
+// issue time a wave costs its SIMD, relative to one of >= 3 resident waves
+double issue_share(int64_t k) { return k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0; }
+
 struct Geometry {
   int32_t tile[SODA_HIP_MAX_DIM];
   double ns;          // modelled time of one launch; 0: no model
@@ -380,10 +383,25 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
     int64_t chunks = (n + chunk - 1) / chunk;
     int64_t blocks = others * ((chunks + along - 1) / along);
     int64_t waves = blocks * wpb;
-    int64_t k = (waves + kSimds - 1) / kSimds;
-    if (k >= cap && waves > 0.975 * k * kSimds) ++k;
-    if (k < k_min) k = k_min;
-    double cost = k * (k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0) * (chunk + warm);
+    double cost;
+    const int64_t slots = (int64_t)cap * kSimds;
+    if (waves <= slots) {
+      int64_t k = (waves + kSimds - 1) / kSimds;
+      if (k >= cap && waves > 0.975 * k * kSimds) ++k;
+      if (k < k_min) k = k_min;
+      cost = k * issue_share(k) * (chunk + warm);
+    } else {
+      // more waves than fit at once: whole rounds of `cap` waves per SIMD,
+      // then a ragged one whose few waves issue at a lone wave's rate
+      // (heat3d T = 2, 2-wave blocks, 245 VGPRs: 19 chunks = 2.4 rounds took
+      // 243 us, 16 chunks = 2 rounds 218 us)
+      const int64_t full = waves / slots, rem = waves - full * slots;
+      cost = full * cap * issue_share(cap) * (chunk + warm);
+      if (rem > 0) {
+        const int64_t rk = (rem + kSimds - 1) / kSimds;
+        cost += rk * issue_share(rk) * (chunk + warm);
+      }
+    }
     if (!best || cost < best_cost || (cost == best_cost && chunk > best)) {
       best_cost = cost;
       best = chunk;
@@ -408,6 +426,13 @@ int kernel_geometry(const soda_hip_kernel_desc_t& d, const int32_t* extent,
              "%s was built for rows that are a multiple of %d cells; extent[0] "
              "= %d is not (rebuild the program for this extent)", d.name, d.vec,
              extent[0]);
+    return fail(SODA_HIP_ERR_INVALID, buf);
+  }
+  if (d.max_extent0 > 0 && extent[0] > d.max_extent0) {
+    snprintf(buf, sizeof buf,
+             "%s was built for rows of at most %d cells (one block covers the "
+             "row); extent[0] = %d (rebuild the program for this extent)",
+             d.name, d.max_extent0, extent[0]);
     return fail(SODA_HIP_ERR_INVALID, buf);
   }
   double rows_factor = 1.0;
@@ -452,12 +477,20 @@ int kernel_geometry(const soda_hip_kernel_desc_t& d, const int32_t* extent,
     const int64_t chunks = (n + per_wave - 1) / per_wave;
     const int64_t waves = others * ((chunks + along - 1) / along) * wpb;
     const int pipe = d.pipe > 0 ? d.pipe : 1;
-    int64_t k = (waves + kSimds - 1) / kSimds;
-    if (k < 1) k = 1;
-    const double eff = k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0;
     double steps = per_wave + d.warm - d.warm_saved;
     if (steps < 1) steps = 1;
-    valu_ns = k * eff * steps * d.step_ns / pipe;
+    // SIMD issue time in units of one wave's row step: whole rounds of as
+    // many waves as the registers allow, then the ragged rest (tuned_chunk)
+    const int64_t slots = (int64_t)(d.vgprs > 0 ? waves_per_simd(d.vgprs) : 8) *
+                          kSimds;
+    const int64_t full = waves / slots, rem = waves - full * slots;
+    double share = full * (double)(slots / kSimds) * issue_share(slots / kSimds);
+    if (rem > 0 || full == 0) {
+      int64_t rk = (rem + kSimds - 1) / kSimds;
+      if (rk < 1) rk = 1;
+      share += rk * issue_share(rk);
+    }
+    valu_ns = share * steps * d.step_ns / pipe;
     rows_factor = (per_wave + (double)d.warm) / per_wave;
   }
   if (d.step_ns > 0 || d.bytes_per_cell > 0) {

@@ -547,6 +547,19 @@ SODA_DEV void soda_unpack_frag(T (&dst)[V], const R& raw, int group = 0) {
 // completed (lgkmcnt(0)) before any wave of the block starts the next step.
 // Deliberately NOT __syncthreads(): a workgroup fence would also drain vmcnt,
 // i.e. wait for the global prefetch loads the first wave keeps in flight.
+// value of lane `from` in every lane (a scalar register): the halo cell a
+// strip's neighbour handed over, fed to a DPP shift as its `old` operand
+template <class T>
+SODA_DEV T soda_bcast(T v, int from) {
+  static_assert(sizeof(T) <= 4, "one register");
+  unsigned u = 0;
+  __builtin_memcpy(&u, &v, sizeof(T));
+  u = (unsigned)__builtin_amdgcn_readlane((int)u, from);
+  T r;
+  __builtin_memcpy(&r, &u, sizeof(T));
+  return r;
+}
+
 SODA_DEV void soda_pipe_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

@@ -39,7 +39,7 @@ MAX_PASSES = 8
 MAX_PASS_KERNELS = 16
 MAX_PARAMS = 8
 NAME_LEN = 96
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class KernelDesc(ctypes.Structure):
@@ -59,7 +59,8 @@ class KernelDesc(ctypes.Structure):
               ('step_ns', ctypes.c_float),
               ('warm_saved', ctypes.c_float),
               ('bytes_per_cell', ctypes.c_float),
-              ('lane_redundancy', ctypes.c_float)]
+              ('lane_redundancy', ctypes.c_float),
+              ('max_extent0', ctypes.c_int32)]
 
 
 class PassDesc(ctypes.Structure):
@@ -329,6 +330,7 @@ def make_plan(mod: lower.Module,
       d.warm_saved = float(tune.get('warm_saved') or 0.0)
       d.bytes_per_cell = io_bytes
       d.lane_redundancy = float(tune.get('lane_redundancy') or 1.0)
+      d.max_extent0 = int(tune.get('max_extent0') or 0)
   passes = mod.sorted_passes()
   if len(passes) > MAX_PASSES:
     raise util.SemanticError('more than %d passes' % MAX_PASSES)
@@ -505,6 +507,8 @@ def resolve_options(stencil: core.Stencil,
   out = copy.copy(opts) if opts is not None else lower.LowerOptions()
   if out.vec is None:
     out.vec = pick_vec(stencil, extent)
+  if out.row_cells is None and extent is not None:
+    out.row_cells = int(extent[0])   # lets blocks cover whole rows (xshare)
   if out.peel is None and out.strategy in ('auto', 'march') and \
       lower.march_supported(stencil) is None:
     try:

@@ -386,3 +386,38 @@ def test_counted_waits_are_exact_in_the_compiled_code(built):
   assert set(seen[(True, True)]['loop_waits']) == {8}
   # the compiler-counted build drains at the head of every trip
   assert min(seen[(False, True)]['loop_waits']) == 0
+
+
+def test_row_covering_blocks_in_the_plan(built):
+  """3-D fused kernels built for a known row length: the block's waves cover
+  the row (x-halos through LDS), the descriptor says so, and the library --
+  without a GPU -- shapes launches for rows that fit and refuses longer ones."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('heat3d.soda'), iterate=6)
+  opts = lower.LowerOptions(fuse=(2,), vec=4, peel=0, row_cells=512)
+  mod = lower.lower(stencil, opts)
+  fused = [k for k in mod.kernels if k.tune.get('fused') == 2][0]
+  assert fused.name.endswith('_xs2') and fused.block == (128, 1, 1)
+  assert fused.tile[0] == 512 and fused.tune['max_extent0'] == 512
+  assert fused.tune['lane_redundancy'] == 1.0       # all 64 lanes store
+  text = mod.source
+  assert '__shared__ float soda_xs_g_in[' in text      # the inputs' end cells
+  assert '__shared__ float soda_xs_t0_out[' in text    # and iteration 0's
+  assert text.count('soda_bcast(hv_') > 0
+  # no narrow edge loads in the fused kernel any more
+  body = text[text.index('void __launch_bounds__(128) ' + fused.name):]
+  body = body[:body.index('\nextern "C"')] if '\nextern "C"' in body else body
+  assert 'exb0_' not in body
+  plan = runtime.make_plan(mod, {k.name: dict(vgpr=245) for k in mod.kernels})
+  d = [plan.kernels[i] for i in range(plan.num_kernels)
+       if plan.kernels[i].name.decode() == fused.name][0]
+  assert d.max_extent0 == 512
+  tiles, _ = runtime.plan_geometry(plan, (512, 512, 512))
+  assert tiles[0][0] == 512
+  runtime.plan_geometry(plan, (300, 64, 64))
+  with pytest.raises(util.BackendError, match='at most 512 cells'):
+    runtime.plan_geometry(plan, (768, 64, 64))
+  # without the row length nothing is assumed
+  plain = lower.lower(stencil, lower.LowerOptions(fuse=(2,), vec=4, peel=0))
+  assert not any('_xs' in k.name for k in plain.kernels)

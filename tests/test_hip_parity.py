@@ -559,6 +559,86 @@ def test_stage_pipelined_blocks(built, name, iterate, fuse, pipe, extent):
   _check(stencil, extent, opts, oracle='c')
 
 
+TWO_STAGE_3D = """kernel: smooth3d
+burst width: 64
+unroll factor: 2
+iterate: 4
+input float: a(32, 32, *)
+local float: m(0, 0, 0) = (a(-1, 0, 0) + a(0, 0, 0) + a(1, 0, 0) + a(0, -1, 0) + a(0, 1, 0) + a(0, 0, 1)) * 0.125f
+output float: b(0, 0, 0) = m(0, 0, -1) * 0.25f + (m(-1, 0, 0) + m(1, 0, 0)) * 0.125f + m(0, 0, 0) * 0.25f + m(0, 0, 1) * 0.25f
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,iterate,opts,extent,waves,border', [
+    ('heat3d.soda', 4, dict(fuse=(2,)), (512, 16, 20), 2, None),
+    ('heat3d.soda', 6, dict(fuse=(2,)), (300, 21, 24), 2, None),   # ragged strip
+    ('heat3d.soda', 5, dict(fuse=(2,)), (256, 12, 18), 1, None),   # one strip: no neighbour
+    ('heat3d.soda', 4, dict(fuse=(2,)), (64, 9, 40), 1, None),
+    ('heat3d.soda', 2, dict(fuse=(2,)), (1024, 9, 12), 4, None),
+    ('jacobi3d.soda', 4, dict(fuse=(2,)), (508, 14, 16), 2, None),
+    ('heat3d.soda', 5, dict(fuse=(2,)), (300, 24, 40), 2, 'preserve'),
+    (TWO_STAGE_3D, 4, dict(fuse=(2,)), (384, 13, 17), 2, None),    # a local crosses strips too
+    # 2-D on request: 4, 8 and 12 fused iterations, up to 3 strips side by side
+    ('jacobi2d.soda', 9, dict(fuse=(4,), xshare=True), (512, 130), 2, None),
+    ('jacobi2d.soda', 16, dict(fuse=(8,), xshare=True), (700, 90), 3, None),
+    ('jacobi2d.soda', 12, dict(fuse=(12,), xshare=True), (256, 200), 1, None),
+    # taps that reach two cells, or touch the newest plane: the generator
+    # falls back to overlapping strips (waves = 0)
+    ('blur.soda', 4, dict(fuse=(2,), xshare=True), (1024, 50), 0, None),
+    ('coupled2d.soda', 4, dict(fuse=(2,), xshare=True), (300, 90), 0, None),
+])
+def test_rows_shared_by_the_waves_of_a_block(built, name, iterate, opts, extent,
+                                              waves, border):
+  """Fused kernels whose block covers the whole row (MarchConfig.xshare): every
+  wave a strip of 64 valid lanes, the strips' end cells -- of the inputs and of
+  every fused iteration's intermediate result -- handed to the neighbours
+  through LDS, one barrier per row step.  Bit-identical to the oracle."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  kw = dict(iterate=iterate)
+  if border:
+    kw['border'] = border
+  if name.endswith('.soda'):
+    stencil = core.from_file(soda_path(name), **kw)
+  else:
+    stencil = core.from_text(name, **kw)
+  lo = lower.LowerOptions(**opts)
+  mod = lower.lower(stencil, runtime.resolve_options(stencil, lo, extent))
+  fused = [k for k in mod.kernels if k.tune and k.tune.get('fused', 1) > 1]
+  assert fused
+  if waves:
+    assert all(k.name.endswith('_xs%d' % waves) for k in fused), \
+        [k.name for k in mod.kernels]
+    assert all(k.tune['max_extent0'] >= extent[0] for k in fused)
+  else:
+    assert not any('_xs' in k.name or k.tune['max_extent0'] for k in fused)
+  _check(stencil, extent, lo, oracle='c')
+
+
+@pytest.mark.gpu
+def test_row_covering_kernels_refuse_longer_rows(built):
+  """A kernel built for rows of <= 512 cells has no strip for cell 512: the
+  library returns SODA_HIP_ERR_INVALID instead of computing a seam wrongly."""
+  import torch
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('heat3d.soda'), iterate=2)
+  with runtime.Program(stencil, lower.LowerOptions(fuse=(2,)),
+                       extent=(512, 16, 12)) as prog:
+    a = torch.rand((12, 16, 768), device='cuda')
+    b = torch.full_like(a, -1.0)
+    lib = runtime.library()
+    outs = (ctypes.c_void_p * 1)(b.data_ptr())
+    ins = (ctypes.c_void_p * 1)(a.data_ptr())
+    ext = (ctypes.c_int32 * 3)(768, 16, 12)
+    rc = lib.soda_hip_run_device(prog._handle, outs, ins, ext, 2, None)
+    assert rc == 1, rc                      # SODA_HIP_ERR_INVALID
+    assert 'at most 512 cells' in runtime.last_error()
+    torch.cuda.synchronize()
+    assert bool((b == -1.0).all())
+
+
 @pytest.mark.parametrize('name,iterate,opts,extent', [
     ('jacobi2d.soda', 1, dict(), (520, 61)),
     ('jacobi2d.soda', 9, dict(fuse=(4,)), (520, 61)),          # 4 + 4 + 1
