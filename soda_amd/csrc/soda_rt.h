@@ -551,12 +551,13 @@ SODA_DEV void soda_unpack_frag(T (&dst)[V], const R& raw, int group = 0) {
 // strip's neighbour handed over, fed to a DPP shift as its `old` operand
 template <class T>
 SODA_DEV T soda_bcast(T v, int from) {
-  static_assert(sizeof(T) <= 4, "one register");
-  unsigned u = 0;
-  __builtin_memcpy(&u, &v, sizeof(T));
-  u = (unsigned)__builtin_amdgcn_readlane((int)u, from);
+  static_assert(sizeof(T) <= 8, "one or two registers");
+  unsigned u[2] = {0u, 0u};
+  __builtin_memcpy(u, &v, sizeof(T));
+  u[0] = (unsigned)__builtin_amdgcn_readlane((int)u[0], from);
+  if (sizeof(T) > 4) u[1] = (unsigned)__builtin_amdgcn_readlane((int)u[1], from);
   T r;
-  __builtin_memcpy(&r, &u, sizeof(T));
+  __builtin_memcpy(&r, u, sizeof(T));
   return r;
 }
 

@@ -569,6 +569,15 @@ output float: b(0, 0, 0) = m(0, 0, -1) * 0.25f + (m(-1, 0, 0) + m(1, 0, 0)) * 0.
 """
 
 
+DOUBLE_2D = """kernel: jacobi2d_f64
+burst width: 64
+unroll factor: 2
+iterate: 4
+input double: a(32, *)
+output double: b(0, 0) = (a(0, 1) + a(1, 0) + a(0, 0) + a(-1, 0) + a(0, -1)) * 0.2
+"""
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,iterate,opts,extent,waves,border', [
     ('heat3d.soda', 4, dict(fuse=(2,)), (512, 16, 20), 2, None),
@@ -583,6 +592,7 @@ output float: b(0, 0, 0) = m(0, 0, -1) * 0.25f + (m(-1, 0, 0) + m(1, 0, 0)) * 0.
     ('jacobi2d.soda', 9, dict(fuse=(4,), xshare=True), (512, 130), 2, None),
     ('jacobi2d.soda', 16, dict(fuse=(8,), xshare=True), (700, 90), 3, None),
     ('jacobi2d.soda', 12, dict(fuse=(12,), xshare=True), (256, 200), 1, None),
+    (DOUBLE_2D, 4, dict(fuse=(2,), xshare=True), (200, 60), 2, None),   # 8-byte cells
     # taps that reach two cells, or touch the newest plane: the generator
     # falls back to overlapping strips (waves = 0)
     ('blur.soda', 4, dict(fuse=(2,), xshare=True), (1024, 50), 0, None),
