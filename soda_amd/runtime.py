@@ -351,12 +351,17 @@ def make_plan(mod: lower.Module,
 def kernel_resources(code: bytes) -> Dict[str, dict]:
   """Per-kernel register/LDS use read from the code object's AMDGPU metadata
   note (msgpack): {kernel name: {'vgpr': n, 'sgpr': n, 'lds': bytes,
-  'scratch': bytes}}.  Returns {} if the note cannot be read."""
+  'scratch': bytes, 'code': bytes of machine code}}.  Returns {} if the note
+  cannot be read."""
   import struct
   try:
     import msgpack
     if code[:4] != b'\x7fELF':
       return {}
+    try:
+      sizes = _function_sizes(code)
+    except Exception:
+      sizes = {}
     shoff, = struct.unpack_from('<Q', code, 0x28)
     shentsize, shnum = struct.unpack_from('<HH', code, 0x3A)
     for i in range(shnum):
@@ -381,11 +386,32 @@ def kernel_resources(code: bytes) -> Dict[str, dict]:
                 vgpr=k.get('.vgpr_count', 0) + 0, sgpr=k.get('.sgpr_count', 0),
                 agpr=k.get('.agpr_count', 0),
                 lds=k.get('.group_segment_fixed_size', 0),
-                scratch=k.get('.private_segment_fixed_size', 0))
+                scratch=k.get('.private_segment_fixed_size', 0),
+                code=sizes.get(k['.name'], 0))
           return out
   except Exception:
     return {}
   return {}
+
+
+def _function_sizes(code: bytes) -> Dict[str, int]:
+  """{function symbol: bytes of machine code} from the ELF symbol table."""
+  import struct
+  out: Dict[str, int] = {}
+  shoff, = struct.unpack_from('<Q', code, 0x28)
+  shentsize, shnum = struct.unpack_from('<HH', code, 0x3A)
+  heads = [struct.unpack_from('<IIQQQQIIQQ', code, shoff + i * shentsize)
+           for i in range(shnum)]
+  for h in heads:
+    if h[1] != 2:                     # SHT_SYMTAB
+      continue
+    str_off = heads[h[6]][4]          # sh_link -> its string table
+    for pos in range(h[4], h[4] + h[5], 24):
+      st_name, st_info, _, _, _, st_size = struct.unpack_from('<IBBHQQ', code, pos)
+      if st_info & 0xF == 2:          # STT_FUNC
+        end = code.index(b'\0', str_off + st_name)
+        out[code[str_off + st_name:end].decode()] = st_size
+  return out
 
 
 NUM_CUS = 256          # MI355X: 8 XCDs x 32 CUs, 4 SIMDs each
@@ -433,16 +459,27 @@ def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
   return vec
 
 
-def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions'
-                ) -> Dict[int, int]:
+ICACHE_BYTES = 60 * 1024   # instruction cache a kernel's loop should stay in
+
+
+def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions',
+                extent: Optional[Sequence[int]] = None) -> Dict[int, int]:
   """{fusion depth: trips of the loop whose warm-up to peel} for the marching
   kernels of `stencil` under `opts` (MarchConfig.peel).  Peeling skips stages
   that do not matter yet -- less work per chunk -- but the late, nearly full
   trips buy little and the straight-line code can need more registers than the
   loop.  Occupancy decides: per depth, the largest trip count whose COMPILED
   kernel keeps the waves per SIMD of the unpeeled kernel and spills nothing
-  (jacobi2d T=12: 2 of 4 trips, 158 VGPRs; all 4 would take 231).  Trials are
-  JIT-compiled (no GPU needed) and remembered in the kernel cache."""
+  (jacobi2d T=12: 2 of 4 trips, 158 VGPRs; all 4 would take 231).  Code size
+  decides too: the peeled steps are whole trips of the unrolled loop, and a
+  3-D kernel's trip is big -- heat3d T=2: 42 KB of code unpeeled, 73 KB with
+  its one trip peeled, past the instruction cache, 220-230 us against 202-205
+  on 512^3.  Where chunks are long (>= 8x the warm-up, judged by the library's
+  geometry for `extent`) the warm-up is a few percent and the smaller code
+  wins; on a thin slab (80 planes: chunks of 8-10) peeling wins, 38 against
+  69 us, also because the peeled kernel happens to need fewer registers.
+  Trials are JIT-compiled (no GPU needed) and remembered in the kernel
+  cache."""
   import copy
   import json
   plain = copy.copy(opts)
@@ -454,7 +491,21 @@ def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions'
       todo[k.tune['fused']] = k.tune['peel_trips_max']
   if not todo:
     return {}
-  key = hashlib.sha256(('peel\0' + '\0'.join(COMPILE_OPTIONS) + '\0' +
+  # long chunks on this extent?  (geometry of the unpeeled kernels)
+  long_chunks = {}
+  res0 = kernel_resources(compile_source(mod0.source,
+                                         '%s.hip' % stencil.app_name))
+  if extent is not None:
+    try:
+      tiles, _ = plan_geometry(make_plan(mod0, res0), extent)
+      for k, tile in zip(mod0.kernels, tiles):
+        if k.tune and k.tune.get('fused') in todo:
+          long_chunks[k.tune['fused']] = \
+              tile[k.tune['axis']] >= 8 * max(1, k.tune.get('warm') or 1)
+    except util.SodaError:
+      pass
+  key = hashlib.sha256(('peel2\0' + '\0'.join(COMPILE_OPTIONS) + '\0' +
+                        repr(sorted(long_chunks.items())) + '\0' +
                         mod0.source).encode()).hexdigest()[:24]
   memo = os.path.join(CACHE_DIR, 'peel_%s.json' % key)
   try:
@@ -464,16 +515,20 @@ def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions'
     pass
 
   def probe(depth: int, trips: int):
-    one = copy.copy(opts)
-    one.fuse = (depth,) if depth > 1 else ()
-    one.peel = trips
-    mod = lower.lower(stencil, one)
-    res = kernel_resources(compile_source(mod.source,
-                                          '%s.hip' % stencil.app_name))
+    if trips == 0:
+      res, mod = res0, mod0
+    else:
+      one = copy.copy(opts)
+      one.fuse = (depth,) if depth > 1 else ()
+      one.peel = trips
+      mod = lower.lower(stencil, one)
+      res = kernel_resources(compile_source(mod.source,
+                                            '%s.hip' % stencil.app_name))
     for k in mod.kernels:
       if k.tune and k.tune.get('fused') == depth:
         r = res.get(k.name)
-        return None if not r else (waves_per_simd(r['vgpr']), r['scratch'])
+        return None if not r else (waves_per_simd(r['vgpr']), r['scratch'],
+                                   r.get('code', 0))
     return None
 
   chosen = {}
@@ -484,9 +539,12 @@ def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions'
       continue
     for trips in range(most, 0, -1):
       got = probe(depth, trips)
-      if got is not None and got[0] >= base[0] and got[1] <= base[1]:
-        chosen[depth] = trips
-        break
+      if got is None or got[0] < base[0] or got[1] > base[1]:
+        continue
+      if long_chunks.get(depth) and got[2] > ICACHE_BYTES >= base[2]:
+        continue          # the warm-up is small change here; keep the code small
+      chosen[depth] = trips
+      break
   try:
     os.makedirs(CACHE_DIR, exist_ok=True)
     tmp = '%s.%d.tmp' % (memo, os.getpid())
@@ -512,7 +570,7 @@ def resolve_options(stencil: core.Stencil,
   if out.peel is None and out.strategy in ('auto', 'march') and \
       lower.march_supported(stencil) is None:
     try:
-      out.peel = select_peel(stencil, out)
+      out.peel = select_peel(stencil, out, extent)
     except util.SemanticError:
       out.peel = 0
   return out

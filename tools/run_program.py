@@ -20,6 +20,8 @@ ap.add_argument('--border', default=None)
 ap.add_argument('--pipe-rows', type=int, default=2)
 ap.add_argument('--shift', default='dpp')
 ap.add_argument('--chunk', type=int, default=0)
+ap.add_argument('--peel', type=int, default=None)
+ap.add_argument('--xshare', type=int, default=None)
 args = ap.parse_args()
 path = args.soda if os.path.exists(args.soda) else os.path.join(ROOT, 'tests/golden/soda', args.soda)
 st = core.from_file(path, iterate=args.iterate, border=args.border)
@@ -28,7 +30,7 @@ shape = tuple(args.extent[::-1])
 dev = torch.device('cuda', 0)
 ins = [torch.rand(shape, device=dev, dtype=T[t.np_name]) if T[t.np_name].is_floating_point else torch.randint(0, 200, shape, device=dev, dtype=T[t.np_name]) for t in st.input_types]
 outs = [torch.empty(shape, device=dev, dtype=T[t.np_name]) for t in st.output_types]
-prog = runtime.Program(st, lower.LowerOptions(strategy=args.strategy, fuse=tuple(args.fuse), pipe=args.pipe, pipe_rows=args.pipe_rows, lane_shift=args.shift, chunk_rows=args.chunk or None), extent=args.extent)
+prog = runtime.Program(st, lower.LowerOptions(strategy=args.strategy, fuse=tuple(args.fuse), pipe=args.pipe, pipe_rows=args.pipe_rows, lane_shift=args.shift, chunk_rows=args.chunk or None, peel=args.peel, xshare=None if args.xshare is None else bool(args.xshare)), extent=args.extent)
 s = torch.cuda.current_stream().cuda_stream
 a, b = runtime.Event(), runtime.Event()
 prog.run_device([t.data_ptr() for t in outs], [t.data_ptr() for t in ins], args.extent, stream=s)
