@@ -113,3 +113,47 @@ def test_gpu_matches_oracle_with_preserved_border(built, seed):
       assert np.array_equal(got[o], want[o], equal_nan=True), (
           'seed %d, %s (%s), output %s: %d cells differ\n%s' %
           (seed, strategy, kinds, o, int((got[o] != want[o]).sum()), text))
+
+
+# seeds (found by scanning 160..1200 on the CPU) whose programs are iterated,
+# fusable and tap one cell to either side: the shapes whose fused kernels can
+# hand x-halos between strips through LDS -- 1, 2 and 3 strips, 2-D and 3-D,
+# several tensors and types
+XSHARE_SEEDS = [253, 261, 304, 306, 379, 396, 434, 457, 475, 507, 518, 533,
+                589, 594, 626, 660, 663, 687, 730, 733, 839, 875, 940, 989,
+                994, 1049, 1129, 1179]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', XSHARE_SEEDS)
+def test_gpu_matches_oracle_with_shared_rows(built, seed):
+  """Random programs on the row-covering kernels (x-halos through LDS,
+  MarchConfig.xshare), forced also in 2-D: bit-identical to the oracle."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  text, stencil, extent = _build(seed)
+  ins = fuzz.inputs_for(stencil, extent, seed)
+  want = c_oracle.COracle(stencil, openmp=False).run(ins)
+  opts = lower.LowerOptions(fuse=(2,), xshare=True)
+  with runtime.Program(stencil, opts, extent=extent) as prog:
+    names = [k.name for k in prog.module.kernels]
+    assert any('_xs' in n for n in names), names
+    got = prog.run(ins)
+  for o in stencil.output_names:
+    lo, hi = stencil.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    g, w = got[o][idx], want[o][idx]
+    assert np.array_equal(g, w, equal_nan=True), (
+        'seed %d (%s), output %s: %d cells differ\n%s' %
+        (seed, names, o, int((g != w).sum()), text))
+  try:
+    kept = core.from_text(text, border='preserve')
+    kept.check_preserve()
+  except util.SodaError:
+    return
+  want = c_oracle.COracle(kept, openmp=False).run(ins)
+  with runtime.Program(kept, opts, extent=extent) as prog:
+    got = prog.run(ins)
+  for o in kept.output_names:     # the WHOLE grid is defined
+    assert np.array_equal(got[o], want[o], equal_nan=True), (seed, o, text)
