@@ -816,10 +816,13 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipMemsetAsync");
   }
   std::vector<double> ns(plan.num_passes, 0.0);
-  // one event pair per pass, recorded in the LAST of four rounds over all the
-  // passes; nothing synchronises in between, so the GPU never idles and the
-  // timed round runs at the clocks a long run holds (a burst of launches a
-  // millisecond after idle reads 20-30 % slow, and not equally per pass)
+  // Two rounds over all the passes bring the clocks to what a long run holds
+  // (a burst of launches a millisecond after idle reads 20-30 % slow, and not
+  // equally per pass); then every pass runs twice back to back, the second
+  // run inside an event pair -- a schedule runs a pass many times in a row,
+  // and the first launches behind a different kernel are not representative
+  // (jacobi2d T = 12 right behind the memory-bound T = 1: 167 us, sustained
+  // 146).  Nothing synchronises in between, so the GPU never idles.
   std::vector<hipEvent_t> ev(2 * plan.num_passes, nullptr);
   for (auto& e : ev)
     if (rc == SODA_HIP_OK && hipEventCreate(&e) != hipSuccess)
@@ -830,14 +833,20 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
       ins.push_back(bufs[plan.num_inputs + plan.num_outputs + k].ptr);
     for (int o = 0; o < plan.num_outputs; ++o)
       outs.push_back(bufs[plan.num_inputs + o].ptr);
-    for (int round = 0; round < 4 && rc == SODA_HIP_OK; ++round)
-      for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
-        const int32_t iters = plan.passes[i].fused_iters * launches;
-        if (round == 3) (void)hipEventRecord(ev[2 * i], stream);
+    for (int round = 0; round < 2 && rc == SODA_HIP_OK; ++round)
+      for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i)
         rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
-                      iters, stream_, i);
-        if (round == 3) (void)hipEventRecord(ev[2 * i + 1], stream);
-      }
+                      plan.passes[i].fused_iters * launches, stream_, i);
+    for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
+      const int32_t iters = plan.passes[i].fused_iters * launches;
+      rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
+                    iters, stream_, i);
+      if (rc != SODA_HIP_OK) break;
+      (void)hipEventRecord(ev[2 * i], stream);
+      rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
+                    iters, stream_, i);
+      (void)hipEventRecord(ev[2 * i + 1], stream);
+    }
     if (rc == SODA_HIP_OK && hipStreamSynchronize(stream) != hipSuccess)
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipStreamSynchronize");
     for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
