@@ -44,8 +44,11 @@ def add_arguments(parser) -> None:
                       help='kernel family: register-marching wavefront strips '
                       '(2-D / 3-D programs) or the direct kernels')
   parser.add_argument('--hip-fuse', type=int, nargs='*', dest='hip_fuse',
-                      metavar='T', default=[4],
-                      help='temporal blocking: iterations fused per launch')
+                      metavar='T', default=[12, 8, 4],
+                      help='temporal blocking: the numbers of iterations a '
+                      'launch may fuse; the library mixes them per extent '
+                      '(default: 12 8 4; depths that do not fit the registers '
+                      'are dropped, 3-D programs fuse at most 2)')
   parser.add_argument('--hip-vec', type=int, dest='hip_vec', metavar='V',
                       help='cells per lane per row (default: 16 bytes worth)')
   parser.add_argument('--hip-chunk-rows', type=int, dest='hip_chunk_rows',
