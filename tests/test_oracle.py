@@ -450,3 +450,23 @@ def test_contrast_follows_the_reference_rebalance(kat):
   # rebalanced sum in dozens of cells.  Any re-associated evaluation -- an
   # MFMA fma chain included -- is in the same position.
   assert numpy_oracle.compare(plain, want, lo, hi) >= 10
+  # The evaluation most favourable to an MFMA path: the reference's own seven
+  # groups in their textual tap order, only with every multiply-add FUSED --
+  # one rounding per term, what `v_mfma_f32_*` does along K.  (fp64 holds the
+  # product of two fp32 exactly; the double rounding of the sum is far below
+  # the effect measured.)  It still fails the compare rule in several cells.
+  fused = np.zeros_like(a)
+  hh, ww = hi[1] - lo[1], hi[0] - lo[0]
+  parts = []
+  for g0 in range(0, len(taps), 32):
+    acc = None
+    for x, y, c in taps[g0:g0 + 32]:
+      term = a[y:y + hh, x:x + ww].astype(np.float64) * np.float64(np.float32(c))
+      acc = term.astype(np.float32) if acc is None else \
+          (acc.astype(np.float64) + term).astype(np.float32)
+    parts.append(acc)
+  total = parts[-1]
+  for part in parts[:-1]:
+    total = total + part
+  fused[idx] = total
+  assert numpy_oracle.compare(fused, want, lo, hi) >= 3
