@@ -274,8 +274,17 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     # within the register budget (else the leanest); only if none exists fall
     # back to `direct` kernels.
     budget = opts.reg_budget or REG_BUDGET
-    pfs = [opts.prefetch] if opts.prefetch else [
-        default_prefetch(1) if stencil.dim == 2 else 1, 2, 1]
+    # arithmetic per cell of one iteration: a program that computes for
+    # hundreds of instructions per cell has nothing to hide behind a deep
+    # prefetch queue and pays for its registers in resident waves (contrast,
+    # 393 operations per cell: 703 us at 8 rows in flight, 660 at 2)
+    from soda_amd import ir
+    work = sum(ir.op_count(s.stmt.expr) +
+               sum(ir.op_count(l.expr) for l in s.stmt.let)
+               for s in stencil.ordered_stages)
+    first = default_prefetch(1) if stencil.dim == 2 and work < 128 else \
+        (2 if stencil.dim == 2 else 1)
+    pfs = [opts.prefetch] if opts.prefetch else [first, 2, 1]
     pfs = sorted(set(pfs), reverse=True)
     # (3-D: fewer rows per tile never paid -- denoise3d 512^3: 651 / 691 / 910
     # us at 4 / 2 / 1 rows, 1 cell per lane -- so the tile height stays)
