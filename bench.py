@@ -241,7 +241,7 @@ def main():
   def step_fn(dst, src, lext, iters):
     prog.run_device([t.data_ptr() for t in dst], [t.data_ptr() for t in src],
                     lext, iterate=iters, stream=stream, origin=slab.origin,
-                    global_extent=slab.extent)
+                    global_extent=slab.extent, keep=slab.keep)
 
   # A sustained iterated run: the input of a step is the output of the step
   # before it.  On N > 1 GPUs the ghost rows of that input are stale, so every

@@ -230,6 +230,25 @@ int soda_hip_run_device_window(soda_hip_program_t* program,
                                const int32_t* extent, const int32_t* origin,
                                const int32_t* global_extent, int32_t iterate,
                                void* stream);
+
+/* Same, when the caller needs only part of the result: the cells [keep_lo,
+ * keep_hi) along the LAST dimension (a slab's own rows -- its ghost rows are
+ * refreshed by the next halo exchange anyway).  One iteration reads `reach_lo`
+ * cells below and `reach_hi` above a cell along that dimension.  Every pass is
+ * then launched only on the rows the iterations still to come can carry into
+ * the kept range (a cone that narrows pass by pass); outside it the outputs
+ * are unspecified.  A side with keep_lo = 0 (keep_hi = extent) is never
+ * trimmed.  The reference has no counterpart: its host tiles with a
+ * replicated halo and recomputes all of it (frt/host.py:124-128). */
+int soda_hip_run_device_cone(soda_hip_program_t* program,
+                             void* const* outputs, const void* const* inputs,
+                             const int32_t* extent, const int32_t* origin,
+                             const int32_t* global_extent, int32_t iterate,
+                             int32_t keep_lo, int32_t keep_hi,
+                             int32_t reach_lo, int32_t reach_hi, void* stream);
+/* Cells along the last dimension the launches of the last run covered, summed
+ * over the launches (a run that trims reports fewer than launches x extent). */
+int soda_hip_last_rows(soda_hip_program_t* program, int64_t* rows);
 int soda_hip_run_device(soda_hip_program_t* program, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,
                         int32_t iterate, void* stream);

@@ -473,6 +473,11 @@ class Stencil:
                for d in range(self.dim))
     return lo, hi
 
+  def reach_along(self, d: int) -> Tuple[int, int]:
+    """Cells one iteration reads below / above a cell along dimension d."""
+    lo, hi = self.radius
+    return -lo[d], hi[d]
+
   # -- windows: point sets (small cases; pins kStencilDistance etc.) -------
   def stencil_window_points(self, name: Optional[str] = None,
                             iterate: Optional[int] = None,

@@ -80,9 +80,13 @@ struct soda_hip_program {
   std::vector<DeviceBuffer> host_out;
   int32_t last_launches = 0;
   int32_t last_fused = 0;
+  int64_t last_rows = 0;     // cells along the last dimension, summed over launches
   void* debug = nullptr;              // time-stamp buffer of diagnostic builds
   // measured time of one launch of every pass, per extent (calibrate)
   std::map<std::array<int32_t, SODA_HIP_MAX_DIM>, std::vector<double>> measured;
+  // tile of every kernel on the sub-extents cone-trimmed runs launch on
+  std::map<std::array<int32_t, SODA_HIP_MAX_DIM>,
+           std::vector<std::array<int32_t, SODA_HIP_MAX_DIM>>> sub_tiles;
 };
 
 struct soda_hip_event {
@@ -646,10 +650,18 @@ int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
                                     nullptr, iterate, stream_);
 }
 
+// rows (cells along the last dimension) a run must deliver, and how far one
+// iteration reaches beyond a row on either side: passes may then skip the rows
+// whose results no later iteration of the run can carry into [keep_lo, keep_hi)
+struct Cone {
+  int32_t keep_lo, keep_hi, reach_lo, reach_hi;
+};
+
 static int run_core(soda_hip_program_t* p, void* const* outputs,
                     const void* const* inputs, const int32_t* extent,
                     const int32_t* origin, const int32_t* global_extent,
-                    int32_t iterate, void* stream_, int force_pass);
+                    int32_t iterate, void* stream_, int force_pass,
+                    const Cone* cone = nullptr);
 
 int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
                                const void* const* inputs,
@@ -660,11 +672,32 @@ int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
                   stream_, -1);
 }
 
+int soda_hip_run_device_cone(soda_hip_program_t* p, void* const* outputs,
+                             const void* const* inputs, const int32_t* extent,
+                             const int32_t* origin,
+                             const int32_t* global_extent, int32_t iterate,
+                             int32_t keep_lo, int32_t keep_hi,
+                             int32_t reach_lo, int32_t reach_hi,
+                             void* stream_) {
+  if (!p || !extent)
+    return fail(SODA_HIP_ERR_INVALID, "run_device_cone: NULL argument");
+  const int ax = p->plan.dim - 1;
+  if (keep_lo < 0 || keep_hi > extent[ax] || keep_lo >= keep_hi ||
+      reach_lo < 0 || reach_hi < 0)
+    return fail(SODA_HIP_ERR_INVALID,
+                "run_device_cone: [keep_lo, keep_hi) must be a non-empty range "
+                "of the last dimension, the reaches non-negative");
+  const Cone cone = {keep_lo, keep_hi, reach_lo, reach_hi};
+  return run_core(p, outputs, inputs, extent, origin, global_extent, iterate,
+                  stream_, -1, &cone);
+}
+
 // force_pass >= 0: use only that pass (calibration)
 static int run_core(soda_hip_program_t* p, void* const* outputs,
                     const void* const* inputs, const int32_t* extent,
                     const int32_t* origin, const int32_t* global_extent,
-                    int32_t iterate, void* stream_, int force_pass) {
+                    int32_t iterate, void* stream_, int force_pass,
+                    const Cone* cone) {
   if (!p || !outputs || !inputs || !extent)
     return fail(SODA_HIP_ERR_INVALID, "run_device: NULL argument");
   const soda_hip_plan_t& plan = p->plan;
@@ -752,8 +785,11 @@ static int run_core(soda_hip_program_t* p, void* const* outputs,
 
   p->last_launches = 0;
   p->last_fused = 0;
+  p->last_rows = 0;
   std::vector<const void*> src(inputs, inputs + plan.num_inputs);
-  int done = 0;
+  const int ax = plan.dim - 1;
+  const int32_t rows = base.extent[ax];
+  int done = 0, done_iters = 0;
   for (int i = 0; i < plan.num_passes; ++i) {
     for (int c = 0; c < count[i]; ++c, ++done) {
       // the last pass writes the caller's outputs; before that alternate
@@ -763,9 +799,53 @@ static int run_core(soda_hip_program_t* p, void* const* outputs,
         base.buf[in0 + j] = const_cast<void*>(src[j]);
       for (int o = 0; o < plan.num_outputs; ++o)
         base.buf[out0 + o] = to_out ? outputs[o] : p->temps[o].ptr;
+      // Rows this pass has to touch.  With a cone: the rows it must DELIVER
+      // are those the iterations still to come can carry into the kept range;
+      // it is launched on these plus the rows its own iterations read beyond
+      // them (their results are written too, and are wrong where the launch
+      // saw zeros instead of neighbours -- nothing reads them again).
+      int32_t lo = 0, hi = rows;
+      const int32_t fused = plan.passes[i].fused_iters;
+      done_iters += fused;
+      if (cone) {
+        const int64_t after = iterate - done_iters;        // iterations to come
+        const int64_t a = cone->keep_lo - (after + fused) * (int64_t)cone->reach_lo;
+        const int64_t b = cone->keep_hi + (after + fused) * (int64_t)cone->reach_hi;
+        if (cone->keep_lo > 0 && a > 0) lo = (int32_t)a;
+        if (cone->keep_hi < rows && b < rows) hi = (int32_t)b;
+      }
+      soda_hip_kargs_t args = base;
+      const std::vector<std::array<int32_t, SODA_HIP_MAX_DIM>>* sub = nullptr;
+      if (lo > 0 || hi < rows) {
+        args.extent[ax] = hi - lo;
+        args.origin[ax] = base.origin[ax] + lo;
+        for (int t = 0; t < plan.num_inputs + plan.num_outputs; ++t)
+          args.buf[t] = static_cast<char*>(base.buf[t]) +
+                        (int64_t)lo * base.stride[ax] * plan.elem_size[t];
+        // (remembered per extent: sizing the chunks of every kernel costs
+        // tens of microseconds of host time, a launch must not)
+        std::array<int32_t, SODA_HIP_MAX_DIM> key;
+        for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = args.extent[d];
+        auto it = p->sub_tiles.find(key);
+        if (it == p->sub_tiles.end()) {
+          std::vector<Geometry> sub_geo;
+          std::vector<double> unused;
+          if (int rc = plan_geometry(plan, args.extent, &sub_geo, &unused))
+            return rc;
+          std::vector<std::array<int32_t, SODA_HIP_MAX_DIM>> tiles(sub_geo.size());
+          for (size_t k = 0; k < sub_geo.size(); ++k)
+            for (int d = 0; d < SODA_HIP_MAX_DIM; ++d)
+              tiles[k][d] = sub_geo[k].tile[d];
+          if (p->sub_tiles.size() > 4096) p->sub_tiles.clear();
+          it = p->sub_tiles.emplace(key, std::move(tiles)).first;
+        }
+        sub = &it->second;
+      }
+      p->last_rows += hi - lo;
       for (int k = 0; k < plan.passes[i].num_kernels; ++k) {
         const int kk = plan.passes[i].kernel[k];
-        int rc = launch(p, kk, base, geo[kk].tile, stream);
+        int rc = launch(p, kk, args,
+                        sub ? (*sub)[kk].data() : geo[kk].tile, stream);
         if (rc) return rc;
         ++p->last_launches;
         if (i == 0) ++p->last_fused;
@@ -904,6 +984,12 @@ int soda_hip_last_launches(soda_hip_program_t* p, int32_t* launches,
   if (!p) return fail(SODA_HIP_ERR_INVALID, "NULL program");
   if (launches) *launches = p->last_launches;
   if (fused_launches) *fused_launches = p->last_fused;
+  return SODA_HIP_OK;
+}
+
+int soda_hip_last_rows(soda_hip_program_t* p, int64_t* rows) {
+  if (!p || !rows) return fail(SODA_HIP_ERR_INVALID, "NULL argument");
+  *rows = p->last_rows;
   return SODA_HIP_OK;
 }
 

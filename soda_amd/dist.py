@@ -76,6 +76,14 @@ class Slab:
     Program.run_device(..., origin=slab.origin, global_extent=slab.extent))."""
     return (0,) * (len(self.extent) - 1) + (self.begin,)
 
+  @property
+  def keep(self) -> Tuple[int, int]:
+    """Local rows a run between two exchanges has to deliver: this rank's own
+    ones (the ghosts are overwritten by the next exchange).  Passed as
+    Program.run_device(..., keep=slab.keep), it lets every pass skip the ghost
+    rows whose results can no longer reach an own row."""
+    return (self.ghost_lo, self.ghost_lo + self.own_rows)
+
   # neighbour traffic, in local row indices: (peer, send rows, recv rows)
   def messages(self) -> List[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
     out = []

@@ -133,6 +133,10 @@ API = {
     'soda_hip_run_device': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _i32, _vp]),
     'soda_hip_run_device_window': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _pi32,
                                                   _pi32, _i32, _vp]),
+    'soda_hip_run_device_cone': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _pi32,
+                                                _pi32, _i32, _i32, _i32, _i32,
+                                                _i32, _vp]),
+    'soda_hip_last_rows': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     'soda_hip_run_host': (ctypes.c_int, [
         _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32
     ]),
@@ -679,12 +683,16 @@ class Program:
   def run_device(self, outputs: Sequence[int], inputs: Sequence[int],
                  extent: Sequence[int], iterate: Optional[int] = None,
                  stream: int = 0, origin: Optional[Sequence[int]] = None,
-                 global_extent: Optional[Sequence[int]] = None) -> None:
+                 global_extent: Optional[Sequence[int]] = None,
+                 keep: Optional[Sequence[int]] = None) -> None:
     """`outputs` / `inputs` are device addresses (e.g. tensor.data_ptr()) of
     dense dim-0-fastest arrays; asynchronous on `stream`.  `inputs` holds the
     input tensors followed by the program's `param` arrays (C order).  For a
     slab of a larger grid pass where its cell 0 sits (`origin`) and the size of
-    the whole grid (`global_extent`): `border: preserve` means the GLOBAL border."""
+    the whole grid (`global_extent`): `border: preserve` means the GLOBAL border.
+    `keep` = (lo, hi): only cells [lo, hi) along the last dimension of the
+    result are needed (a slab's own rows); passes then skip the rows nothing
+    can carry into that range any more (soda_hip_run_device_cone)."""
     st = self.stencil
     iterate = st.iterate if iterate is None else iterate
     self._check_extent(extent)
@@ -696,11 +704,27 @@ class Program:
     ext = (ctypes.c_int32 * len(extent))(*extent)
     org = (ctypes.c_int32 * len(extent))(*(origin or [0] * len(extent)))
     gext = (ctypes.c_int32 * len(extent))(*(global_extent or extent))
+    if keep is not None and tuple(keep) != (0, extent[-1]):
+      reach_lo, reach_hi = st.reach_along(st.dim - 1)
+      check(
+          self._lib.soda_hip_run_device_cone(
+              self._handle, outs, ins, ext, org, gext, iterate, int(keep[0]),
+              int(keep[1]), reach_lo, reach_hi, ctypes.c_void_p(stream)),
+          'running `%s`' % st.app_name)
+      return
     check(
         self._lib.soda_hip_run_device_window(self._handle, outs, ins, ext, org,
                                              gext, iterate,
                                              ctypes.c_void_p(stream)),
         'running `%s`' % st.app_name)
+
+  def last_rows(self) -> int:
+    """Cells along the last dimension the launches of the last run covered,
+    summed over the launches."""
+    n = ctypes.c_int64()
+    check(self._lib.soda_hip_last_rows(self._handle, ctypes.byref(n)),
+          'last_rows')
+    return n.value
 
   def set_debug_buffer(self, ptr: int) -> None:
     """Device buffer the time stamps of `stamps=True` kernels go to."""

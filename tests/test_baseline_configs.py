@@ -109,6 +109,9 @@ def test_eight_slabs_over_thread_fabric_cpu(built, name, extent, iterate,
 # GPU: the configs as written
 # ---------------------------------------------------------------------------
 
+rows = []      # rows the launches of every interval covered (all ranks)
+
+
 def _gpu_engine(stencil, fuse):
   import torch
   from soda_amd import runtime
@@ -123,7 +126,8 @@ def _gpu_engine(stencil, fuse):
       prog.run_device([t.data_ptr() for t in dst],
                       [t.data_ptr() for t in src], lext, iterate=iters,
                       stream=stream, origin=slab.origin,
-                      global_extent=slab.extent)
+                      global_extent=slab.extent, keep=slab.keep)
+      rows.append(prog.last_rows())
 
     def to_host(t):
       torch.cuda.synchronize()

@@ -252,7 +252,8 @@ def _gpu_worker(rank, world, port, name, extent, iterate, every, fuse, out_dir,
     prog.run_device([t.data_ptr() for t in d_out],
                     [t.data_ptr() for t in d_in], lext, iterate=iters,
                     stream=torch.cuda.current_stream().cuda_stream,
-                    origin=slab.origin, global_extent=slab.extent)
+                    origin=slab.origin, global_extent=slab.extent,
+                    keep=slab.keep)
     torch.cuda.synchronize()
     for h, d in zip(dst, d_out):
       h.copy_(d.cpu())

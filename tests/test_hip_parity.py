@@ -627,6 +627,51 @@ def test_rows_shared_by_the_waves_of_a_block(built, name, iterate, opts, extent,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,extent,iterate,fuse,keep', [
+    ('jacobi2d.soda', (520, 400), 40, (12, 4), (100, 300)),     # both sides trimmed
+    ('jacobi2d.soda', (520, 400), 40, (12, 4), (0, 250)),       # a global border below
+    ('jacobi2d.soda', (520, 400), 17, (4,), (150, 400)),        # ... above
+    ('heat3d.soda', (256, 24, 90), 10, (2,), (30, 60)),
+    ('blur.soda', (640, 300), 6, (3,), (40, 200)),              # reaches 0 below, 2 above
+])
+def test_runs_that_keep_a_row_range_skip_the_rest(built, name, extent, iterate,
+                                                  fuse, keep):
+  """soda_hip_run_device_cone: a run that only has to deliver rows [lo, hi)
+  (a slab's own rows) launches every pass on the rows that can still reach
+  them.  The kept rows equal the untrimmed run bit for bit, and the launches
+  covered fewer rows."""
+  import torch
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  ins = _inputs(stencil, extent, 7)
+  with runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
+                       extent=extent) as prog:
+    src = [torch.from_numpy(ins[n]).cuda() for n in stencil.input_names]
+    full = [torch.zeros_like(t) for t in src]
+    part = [torch.full_like(t, 77) for t in src]
+    s = torch.cuda.current_stream().cuda_stream
+    prog.run_device([t.data_ptr() for t in full], [t.data_ptr() for t in src],
+                    extent, stream=s)
+    rows_full = prog.last_rows()
+    launches = prog.last_launches()[0]
+    prog.run_device([t.data_ptr() for t in part], [t.data_ptr() for t in src],
+                    extent, stream=s, keep=keep)
+    rows_part = prog.last_rows()
+    assert prog.last_launches()[0] == launches
+    torch.cuda.synchronize()
+  assert rows_full == launches * extent[-1]
+  assert rows_part < rows_full - 2 * launches      # every pass but the first narrows
+  lo, hi = stencil.valid_box(extent)
+  box = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  a = full[0].cpu().numpy()[box]
+  b = part[0].cpu().numpy()[box]
+  k0, k1 = max(keep[0], lo[-1]) - lo[-1], min(keep[1], hi[-1]) - lo[-1]
+  assert k1 > k0
+  assert np.array_equal(a[k0:k1], b[k0:k1])
+
+
+@pytest.mark.gpu
 def test_row_covering_kernels_refuse_longer_rows(built):
   """A kernel built for rows of <= 512 cells has no strip for cell 512: the
   library returns SODA_HIP_ERR_INVALID instead of computing a seam wrongly."""

@@ -43,7 +43,7 @@ def measure(name, extent, iterate, fuse, world=1, reps=5, label=''):
 
   def go():
     prog.run_device([t.data_ptr() for t in outs], [t.data_ptr() for t in ins],
-                    lext, stream=stream)
+                    lext, stream=stream, keep=slab.keep)
 
   go()
   go()
