@@ -391,8 +391,13 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
     const int64_t slots = (int64_t)cap * kSimds;
     if (waves <= slots) {
       int64_t k = (waves + kSimds - 1) / kSimds;
-      if (k >= cap && waves > 0.975 * k * kSimds) ++k;
-      if (k < k_min) k = k_min;
+      // (one wave per SIMD has nothing to pack: a full grid is fine there --
+      // heat3d T = 2 at 260 VGPRs, 1024 waves of 128 planes: 195 us, two
+      // rounds of 64-plane waves 205)
+      if (cap > 1) {
+        if (k >= cap && waves > 0.975 * k * kSimds) ++k;
+        if (k < k_min) k = k_min;
+      }
       cost = k * issue_share(k) * (chunk + warm);
     } else {
       // more waves than fit at once: whole rounds of `cap` waves per SIMD,
@@ -411,7 +416,9 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
       best = chunk;
     }
   }
-  if (d.warm <= 12 && best > 64) best = 64;   // latency-bound: more, shorter waves
+  // latency-bound: more, shorter waves (not for a kernel the registers allow
+  // one wave per SIMD of: it has no second wave to hide anything behind)
+  if (d.warm <= 12 && best > 64 && cap > 1) best = 64;
   int64_t chunks = (n + best - 1) / best;
   return (int32_t)((n + chunks - 1) / chunks);   // same count, equal lengths
 }
