@@ -246,8 +246,8 @@ int soda_hip_run_device_cone(soda_hip_program_t* program,
                              const int32_t* global_extent, int32_t iterate,
                              int32_t keep_lo, int32_t keep_hi,
                              int32_t reach_lo, int32_t reach_hi, void* stream);
-/* Cells along the last dimension the launches of the last run covered, summed
- * over the launches (a run that trims reports fewer than launches x extent). */
+/* Cells along the last dimension the passes of the last run covered, summed
+ * over the passes (a run that trims reports fewer than passes x extent). */
 int soda_hip_last_rows(soda_hip_program_t* program, int64_t* rows);
 int soda_hip_run_device(soda_hip_program_t* program, void* const* outputs,
                         const void* const* inputs, const int32_t* extent,

@@ -80,7 +80,7 @@ struct soda_hip_program {
   std::vector<DeviceBuffer> host_out;
   int32_t last_launches = 0;
   int32_t last_fused = 0;
-  int64_t last_rows = 0;     // cells along the last dimension, summed over launches
+  int64_t last_rows = 0;     // cells along the last dimension, summed over passes
   void* debug = nullptr;              // time-stamp buffer of diagnostic builds
   // measured time of one launch of every pass, per extent (calibrate)
   std::map<std::array<int32_t, SODA_HIP_MAX_DIM>, std::vector<double>> measured;

@@ -719,8 +719,8 @@ class Program:
         'running `%s`' % st.app_name)
 
   def last_rows(self) -> int:
-    """Cells along the last dimension the launches of the last run covered,
-    summed over the launches."""
+    """Cells along the last dimension the passes of the last run covered,
+    summed over the passes."""
     n = ctypes.c_int64()
     check(self._lib.soda_hip_last_rows(self._handle, ctypes.byref(n)),
           'last_rows')
