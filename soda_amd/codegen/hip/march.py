@@ -155,7 +155,11 @@ class MarchConfig:
     # consuming add), 'bperm' (ds_bpermute_b32, issued one stage early), 'swz'
     # (ds_swizzle rotate + a readlane/writelane patch for the lane that crosses
     # the 32-lane halves) or 'swzh' (ds_swizzle rotate alone: the wave holds
-    # two independent 32-lane half strips, each with its own halo lanes)
+    # two independent 32-lane half strips, each with its own halo lanes) or
+    # 'lds': every lane files the end cells of a row it has computed in a
+    # wave-private LDS line and takes its neighbours' from there one row step
+    # later (plain ds_write / ds_read, no barrier: one wave, in-order LDS), so
+    # the vector ALU sees no cross-lane operation for computed rows at all
     self.lane_shift = lane_shift
     # emit a stage's cells operation-major (independent statements back to
     # back).  Measured SLOWER on gfx950 (T=12: 186 vs 151 us): a wave64 VALU op
@@ -191,6 +195,7 @@ class MarchConfig:
                     '_bp' if self.lane_shift == 'bperm' else
                     '_swz' if self.lane_shift == 'swz' else
                     '_swzh' if self.lane_shift == 'swzh' else
+                    '_ldsx' if self.lane_shift == 'lds' else
                     '_noshift' if self.lane_shift == 'none' else '') + (
                         '_mw%d' % self.min_waves if self.min_waves else '') + (
                             '_occ%d' % self.occupancy if self.occupancy else '') + (
@@ -383,7 +388,7 @@ class _MarchKernel:
     self.edge = (0, 0)
     # lanes that form one strip: the whole wave, or each 32-lane half
     self.group = 32 if self.cfg.lane_shift == 'swzh' else 64
-    if self.cfg.edge_loads and self.cfg.lane_shift in ('dpp', 'none'):
+    if self.cfg.edge_loads and self.cfg.lane_shift in ('dpp', 'none', 'lds'):
       # (the edge cells enter through DPP's `old` operand)
       lo = hi = 0
       for stage in self.st.ordered_stages:
@@ -812,6 +817,57 @@ class _MarchKernel:
     if self.use_bperm:
       self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
       self.w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
+    # 'lds' lane shifts: which computed tensors hand their end cells to the
+    # neighbouring lanes through LDS, and how many cells per side.  A tensor
+    # qualifies when every off-centre tap on it reads the row computed ONE row
+    # step ago (the line holds one row; jacobi-like stencils: taps off-centre
+    # in x sit on the centre row, the newest row is one ahead) and reaches at
+    # most one lane.  The others keep DPP.
+    self.ldsx: Dict[int, Tuple[int, int]] = {}
+    if self.cfg.lane_shift == 'lds' and self.W == 1 and not self.xs and \
+        self.dim == 2:
+      for n in self.nodes:
+        if n.stage is None or n.mirror_of is not None:
+          continue
+        lo = hi = 0
+        ok = True
+        for c in self.nodes:
+          if c.stage is None:
+            continue
+          for pname, pnode in c.parents.items():
+            if pnode is not n:
+              continue
+            for off in c.stage.taps.get(pname, ()):
+              if off[0] == 0:
+                continue
+              first, last = off[0], off[0] + self.V - 1   # cells 0 and V-1
+              if first >= 0 and last < self.V:
+                continue                    # stays inside the lane
+              if c.delay - off[self.ax] - n.fill_delay != 1 or \
+                  abs(off[0]) > self.V:
+                ok = False
+              lo, hi = max(lo, -off[0]), max(hi, off[0])
+        if ok and (lo or hi):
+          self.ldsx[id(n)] = (lo, hi)
+      for n in self.nodes:
+        if id(n) not in self.ldsx:
+          continue
+        lo, hi = self.ldsx[id(n)]
+        # L<i>[j]: cell V-1-i of lane j-1;  R<i>[j]: cell i of lane j
+        for i in range(lo):
+          self.w('  __shared__ %s soda_lx_%s_L%d[65];' % (n.ctype, n.var, i))
+        for i in range(hi):
+          self.w('  __shared__ %s soda_lx_%s_R%d[65];' % (n.ctype, n.var, i))
+      if self.ldsx:
+        self.w('  if (lane == 0) {   // what lies beyond the wave\'s end lanes')
+        for n in self.nodes:
+          if id(n) in self.ldsx:
+            lo, hi = self.ldsx[id(n)]
+            for i in range(lo):
+              self.w('    soda_lx_%s_L%d[0] = (%s)0;' % (n.var, i, n.ctype))
+            for i in range(hi):
+              self.w('    soda_lx_%s_R%d[64] = (%s)0;' % (n.var, i, n.ctype))
+        self.w('  }')
     declared = set()
     for stage in self.st.ordered_stages:      # `param` arrays: plain pointers
       for line in self.mod.param_decls(stage):
@@ -1031,6 +1087,7 @@ class _MarchKernel:
                   n.mirror_of.var, self.R, 2 * self.R - 1, j, self.V))
     # 2. compute every tensor's new plane
     self._shifted: Dict[Tuple[str, int, int, int, int], str] = {}
+    self._lx_read = set()      # ('lds' shifts) lines already read in this step
     self._stage_mark = len(self.L)
     # (tensor, slot) whose end cells change hands at the end of this step: the
     # planes computed in it, and the input plane whose load it is first to use
@@ -1073,6 +1130,20 @@ class _MarchKernel:
       self.w('      soda_pipe_barrier();')
     self.w('    }')
 
+  def _lx_reads(self, n: _Node) -> List[str]:
+    lo, hi = self.ldsx[id(n)]
+    # compiler fences (no instruction): a lane reads what ANOTHER lane wrote,
+    # which single-thread reordering rules know nothing about -- the reads must
+    # stay behind the previous step's writes and ahead of this step's
+    out = ['      asm volatile("" ::: "memory");']
+    for i in range(lo):
+      out.append('      const %s lx_%s_L%d = soda_lx_%s_L%d[lane];'
+                 % (n.ctype, n.var, i, n.var, i))
+    for i in range(hi):
+      out.append('      const %s lx_%s_R%d = soda_lx_%s_R%d[lane + 1];'
+                 % (n.ctype, n.var, i, n.var, i))
+    return out
+
   def _emit_stage(self, n: _Node, k: int) -> None:
     """One tensor's new plane at tick phase k: lane-shifted operands first
     (shared by the stages of a tick), then one statement per cell."""
@@ -1104,6 +1175,16 @@ class _MarchKernel:
         return src
       if self.cfg.lane_shift == 'none':
         return src       # TIMING EXPERIMENTS ONLY: wrong results
+      if id(p) in self.ldsx and abs(lane_off) == 1 and age == 1:
+        # the neighbouring lane filed this cell one row step ago
+        i = (-c - 1) if lane_off < 0 else (c - self.V)
+        name = 'lx_%s_%s%d' % (p.var, 'L' if lane_off < 0 else 'R', i)
+        if (p.var, _k) not in self._lx_read:
+          # (the tensor's own stage is skipped in this peeled step, so its
+          # line still holds the row wanted: read it here)
+          self._lx_read.add((p.var, _k))
+          _pre.extend(self._lx_reads(p))
+        return name
       key = (p.var, slot, row, sub, lane_off)
       if key not in self._shifted:
         tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',
@@ -1232,8 +1313,23 @@ class _MarchKernel:
                        operand(n.keep, zero, j, e), dst))
       body.append('      }')
     self._stage_mark = len(self.L)
+    if id(n) in self.ldsx and (n.var, k) not in self._lx_read:
+      # the cells the neighbouring lanes filed one row step ago, fetched
+      # BEFORE this step's row overwrites the line; consumed by the stages
+      # that follow in this step
+      self._lx_read.add((n.var, k))
+      self.L.extend(self._lx_reads(n))
     self.L.extend(pre)
     self.L.extend(body)
+    if id(n) in self.ldsx:
+      lo, hi = self.ldsx[id(n)]
+      reg = '%s_s%d_r0' % (n.var, dst_slot)
+      self.w('      asm volatile("" ::: "memory");')
+      for i in range(lo):
+        self.w('      soda_lx_%s_L%d[lane + 1] = %s[%d];' %
+               (n.var, i, reg, self.V - 1 - i))
+      for i in range(hi):
+        self.w('      soda_lx_%s_R%d[lane] = %s[%d];' % (n.var, i, reg, i))
     if guard:
       self.w('      }')
       self._shifted = {}

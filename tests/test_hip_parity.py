@@ -264,13 +264,35 @@ def test_explicit_chunk_and_wave_shapes(built):
              dict(chunk_rows=16, prefetch=4, nt_store=True, nt_load=False,
                   xcd_swizzle=False, edge_loads=False),
              dict(warm_guards=True), dict(interleave=True),
-             dict(lane_shift='bperm'), dict(vec=2),
+             dict(lane_shift='bperm'), dict(lane_shift='lds'), dict(vec=2),
              dict(vec=1, chunk_rows=33)):
     _check(stencil, (1000, 200), lower.LowerOptions(fuse=(3,), **kw))
   h = core.from_file(soda_path('heat3d.soda'), iterate=2)
   for kw in (dict(tile_rows=1), dict(tile_rows=6, chunk_rows=5),
              dict(edge_loads=False, prefetch=2)):
     _check(h, (300, 20, 24), lower.LowerOptions(**kw))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,iterate,fuse,extent', [
+    ('jacobi2d.soda', 24, (12,), (1000, 333)),
+    ('jacobi2d.soda', 9, (4,), (520, 97)),
+    ('seidel2d.soda', 8, (8,), (640, 200)),
+    ('blur.soda', 4, (2,), (640, 200)),          # a tap that reaches two cells
+    ('coupled2d.soda', 4, (2,), (300, 90)),      # two tensors per iteration
+])
+def test_lane_neighbours_through_lds(built, name, iterate, fuse, extent):
+  """`lane_shift='lds'`: a lane files the end cells of every computed row in a
+  wave-private LDS line and reads its neighbours' one row step later instead
+  of shifting registers with DPP.  Bit-identical to the oracle."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  mod = lower.lower(stencil, lower.LowerOptions(fuse=fuse, lane_shift='lds',
+                                                vec=4 if name != 'blur.soda' else 8))
+  assert any('_ldsx' in k.name for k in mod.kernels)
+  _check(stencil, extent, lower.LowerOptions(fuse=fuse, lane_shift='lds'),
+         oracle='c')
 
 
 @pytest.mark.parametrize('name,iterate,fuse', [
