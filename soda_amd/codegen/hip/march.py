@@ -744,6 +744,10 @@ class _MarchKernel:
         self.w('  const unsigned pitch_b%d = (unsigned)pitch * %du;' % (es, es))
         if self.dim == 3:
           self.w('  const unsigned pitch_yb%d = (unsigned)pitch_y * %du;' % (es, es))
+          for j in range(self.rows_in):
+            self.w('  const unsigned yo%d_%d = (y0 + %d >= 0 && y0 + %d < n1) ? '
+                   '(unsigned)(y0 + %d) * pitch_yb%d : SODA_OOB_X;' %
+                   (es, j, j, j, j, es))
       for nme, n in self.inputs.items():
         self.w('  const soda_rsrc_t r_%s = soda_make_rsrc((const %s*)a.buf[%d] + '
           '(int64_t)wlo * pitch, (int64_t)(in_end - wlo) * pitch * %d);' %
@@ -924,11 +928,14 @@ class _MarchKernel:
             self.w('      const unsigned ro%d = plane_ok ? (unsigned)(t - wlo) * '
               'pitch_b%d : SODA_OOB_ROW;' % (es, es))
           else:
+            # plane part + row part (loop-invariant, emitted once) + lane
+            # part, each either in range or 2^30: the sum is out of range as
+            # soon as one of them is, and cannot wrap (soda_rt.h)
+            self.w('      const unsigned po%d = plane_ok ? (unsigned)(t - wlo) * '
+              'pitch_b%d : SODA_OOB_X;' % (es, es))
             for j in sorted({j for n in self.inputs.values() for j in self.rows_of(n)}):
-              self.w('      const unsigned ro%d_%d = (plane_ok && y0 + %d >= 0 && '
-                'y0 + %d < n1) ? (unsigned)(t - wlo) * pitch_b%d + '
-                '(unsigned)(y0 + %d) * pitch_yb%d : SODA_OOB_ROW;' %
-                (es, j, j, j, es, j, es))
+              self.w('      const unsigned ro%d_%d = po%d + yo%d_%d;' %
+                     (es, j, es, es, j))
       for nme, n in self.inputs.items():
         s = self.slot_of(n, k, 0)
         for j in (self.rows_of(n) if self.cw else []):
@@ -1353,10 +1360,9 @@ class _MarchKernel:
       for j in self.store_rows(n):
         reg = '%s_s%d_r%d' % (n.var, dst_slot, j)
         if self.dim == 3:
-          self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, ((m_ok && y0 + %d '
-            '< n1) ? (unsigned)(m - m_begin) * pitch_b%d + (unsigned)(y0 + '
-            '%d) * pitch_yb%d : SODA_OOB_ROW) + sxb%d, %s);' %
-            (n.ctype, self.V, self.nt_s, oname, j, es, j, es, es, reg))
+          self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? (unsigned)'
+            '(m - m_begin) * pitch_b%d : SODA_OOB_X) + yo%d_%d + sxb%d, %s);' %
+            (n.ctype, self.V, self.nt_s, oname, es, es, j, es, reg))
         else:
           self.w('        soda_buf_store_frag<%s, %d, %s>(w_%s, (m_ok ? '
             '(unsigned)(m - m_begin) * pitch_b%d : SODA_OOB_ROW) + sxb%d, '

@@ -377,7 +377,10 @@ SODA_DEV void soda_store_frag(T* __restrict__ p, const T (&src)[V]) {
 // Offsets are unsigned bytes from the start of the wave's window of a tensor;
 // the host keeps windows <= SODA_BUF_WINDOW_MAX bytes so that
 //   valid + valid < 2^30,  valid + SODA_OOB_X in [2^30, 2^31),
-//   SODA_OOB_ROW + anything >= 2^31 without wrapping.
+//   SODA_OOB_ROW + anything >= 2^31 without wrapping;
+// 3-D kernels add three parts (plane, row, lane), each in range or
+// SODA_OOB_X: in range together they stay below 2^30, with one to three
+// sentinels the sum lies in [2^30, 2^32) -- out of range, no wrap.
 typedef unsigned soda_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned soda_u32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t soda_rsrc_t;
