@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 5
+#define SODA_HIP_ABI_VERSION 6
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
 #define SODA_HIP_MAX_KERNELS 32
@@ -85,6 +85,19 @@ typedef struct soda_hip_kargs {
                                           multi-GPU run; = 0 / extent else):
                                           `border: preserve` is about the
                                           GLOBAL border */
+  int32_t skip_from;                   /* a launch may cover a marching kernel's
+                                          chunks with a run of them left out:
+                                          block tile t along the streamed
+                                          dimension stands for tile
+                                          t + (t >= skip_from ? skip_count : 0)
+                                          (ntile there = tiles launched).  The
+                                          chunks next to a slab's ghost rows
+                                          and the rest then run as two
+                                          launches, around a halo exchange
+                                          (soda_hip_run_device_slab); 0, 0
+                                          everywhere else */
+  int32_t skip_count;
+  int32_t reserved[2];
 } soda_hip_kargs_t;
 
 typedef struct soda_hip_kernel_desc {
@@ -181,7 +194,8 @@ size_t soda_hip_last_error(char* buf, size_t cap);
 int soda_hip_device_count(int* count);
 /* sizeof() of the ABI structs as this library was compiled, for bindings to
  * check their mirrors: 0 kargs, 1 kernel_desc, 2 pass_desc, 3 plan,
- * 4 host_tensor, 5 stream_desc; 0 for anything else. */
+ * 4 host_tensor, 5 stream_desc, 6 slab_run, 7 group_desc, 8 slab_info,
+ * 9 group_stats, 10 launch_info; 0 for anything else. */
 size_t soda_hip_sizeof(int which);
 
 /* -- JIT: HIP source text -> gfx950 code object (hiprtc; needs no GPU) ---- */
@@ -246,6 +260,60 @@ int soda_hip_run_device_cone(soda_hip_program_t* program,
                              const int32_t* global_extent, int32_t iterate,
                              int32_t keep_lo, int32_t keep_hi,
                              int32_t reach_lo, int32_t reach_hi, void* stream);
+/* Same, for a slab whose ghost rows are refreshed by a halo exchange the
+ * caller runs on another stream -- RCCL send/recv, peer copies; the library
+ * only sees the two events -- so that the exchange hides under the compute:
+ *   ghost_lo / ghost_hi  rows [0, ghost_lo) and [extent - ghost_hi, extent) of
+ *                        the INPUT arrays are being written by an exchange
+ *                        that is complete when `ghosts_ready` (a hipEvent_t)
+ *                        fires.  The chunks of the first pass whose inputs
+ *                        stay clear of these rows are launched at once, the
+ *                        others behind the event.  NULL: the ghosts are fresh;
+ *   send_lo / send_hi    rows [keep_lo, keep_lo + send_lo) and [keep_hi -
+ *                        send_hi, keep_hi) of the RESULT are what the
+ *                        neighbours fetch next.  The chunks of the last pass
+ *                        that deliver them (and everything below / above:
+ *                        the only launches that still write the result's
+ *                        ghost rows) go first, `sendable` (a hipEvent_t,
+ *                        recorded exactly once per call; NULL: none) fires
+ *                        behind them, the rest of the pass follows -- the
+ *                        next exchange may start while it computes.
+ * A split pass runs its two parts on two streams (the boundary chunks on a
+ * stream the program owns, ordered against `stream` by events) so they share
+ * the GPU.  Passes that are not one marching kernel along the last dimension
+ * run whole: wait, compute, signal.  The reference has no counterpart (one
+ * device, frt/host.py:319-322); SURVEY.md 8(e): "compute boundary planes
+ * first, send, compute interior". */
+typedef struct soda_hip_slab_run {
+  int32_t keep_lo, keep_hi;            /* as in soda_hip_run_device_cone */
+  int32_t reach_lo, reach_hi;
+  int32_t ghost_lo, ghost_hi;
+  int32_t send_lo, send_hi;
+  void* ghosts_ready;
+  void* sendable;
+} soda_hip_slab_run_t;
+int soda_hip_run_device_slab(soda_hip_program_t* program, void* const* outputs,
+                             const void* const* inputs, const int32_t* extent,
+                             const int32_t* origin,
+                             const int32_t* global_extent, int32_t iterate,
+                             const soda_hip_slab_run_t* run, void* stream);
+/* The launches a soda_hip_run_device_slab call on `extent` would issue, in
+ * order, by the plan's time model (no GPU, no program; `run` may be NULL, its
+ * two events only count as "given" or not): which rows of the last dimension
+ * every pass covers and how a pass next to the exchange is cut -- block tiles
+ * of `chunk` rows, `chunks` of them, the boundary [0, bnd_lo) U [bnd_hi,
+ * chunks) on the side stream, the interior beside it.  At most `capacity`
+ * entries are written; *count is the number of launches. */
+typedef struct soda_hip_launch_info {
+  int32_t fused_iters;
+  int32_t lo, hi;
+  int32_t wait, record, split;
+  int32_t chunk, chunks, bnd_lo, bnd_hi;
+} soda_hip_launch_info_t;
+int soda_hip_plan_launches(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t iterate, const soda_hip_slab_run_t* run,
+                           int32_t capacity, soda_hip_launch_info_t* launches,
+                           int32_t* count);
 /* Cells along the last dimension the passes of the last run covered, summed
  * over the passes (a run that trims reports fewer than passes x extent). */
 int soda_hip_last_rows(soda_hip_program_t* program, int64_t* rows);
@@ -309,6 +377,116 @@ int soda_hip_program_set_debug_buffer(soda_hip_program_t* program, void* buf);
  * many of them used the pass with the largest fused_iters. */
 int soda_hip_last_launches(soda_hip_program_t* program, int32_t* launches,
                            int32_t* fused_launches);
+/* Passes of the last run that were launched in two parts (boundary chunks /
+ * interior) around a halo exchange. */
+int soda_hip_last_split(soda_hip_program_t* program, int32_t* passes);
+
+/* -- one host thread, N GPUs: a grid cut into slabs -------------------------
+ * The reference's host is one blocking C++ sequence on one device
+ * (frt/host.py:319-322: WriteToDevice, Exec, ReadFromDevice, Finish); its only
+ * scale-out is host-side tiling with a replicated halo that is recomputed
+ * (frt/host.py:124-128,181-249).  A group is the MI355X form of that host
+ * (SURVEY.md 8b "one host thread drives N GPUs (one stream each)", 8e): the
+ * LAST dimension -- the one SODA streams -- is cut into one contiguous slab
+ * per device; every slab keeps `exchange_every x reach` ghost rows per side,
+ * runs that many iterations without communication, then fetches its ghosts
+ * from the neighbours' own rows by peer-to-peer copies (xGMI) on a stream of
+ * its own while the rows that need no fresh ghost keep computing
+ * (soda_hip_run_device_slab).  No collective anywhere.  The result on the
+ * global valid box is the single-device result bit for bit.
+ *
+ * `device[]` may name one GPU several times: such slabs are "virtual devices"
+ * that share it (copies between them are plain device copies).  This is how a
+ * one-GPU box runs the whole N-slab schedule -- streams, events, overlap. */
+#define SODA_HIP_MAX_SLABS 64
+#define SODA_HIP_GROUP_NO_OVERLAP 1    /* exchange, then compute: for A/B runs */
+#define SODA_HIP_GROUP_CALIBRATE 2     /* time every pass on every slab extent
+                                          once (soda_hip_program_calibrate) */
+
+typedef struct soda_hip_group_desc {
+  int32_t num_slabs;
+  int32_t device[SODA_HIP_MAX_SLABS];
+  int32_t extent[SODA_HIP_MAX_DIM];    /* the whole grid */
+  int32_t reach_lo, reach_hi;          /* cells along the last dimension one
+                                          iteration reads below / above a cell
+                                          (the stencil window's extent there:
+                                          ref core.py:876-926) */
+  int32_t iterate;                     /* iterations of a typical run: what the
+                                          exchange interval is chosen for */
+  int32_t exchange_every;              /* iterations between exchanges; 0: the
+                                          library picks the interval of least
+                                          modelled time from its per-extent
+                                          pass times and a transfer model */
+  int32_t flags;                       /* SODA_HIP_GROUP_* */
+} soda_hip_group_desc_t;
+
+typedef struct soda_hip_slab_info {
+  int32_t device;
+  int32_t begin, end;                  /* global rows held: own + ghosts */
+  int32_t own_begin, own_end;
+  int32_t ghost_lo, ghost_hi;
+  int32_t extent[SODA_HIP_MAX_DIM];    /* of the slab's arrays */
+  void* inputs[SODA_HIP_MAX_TENSORS];  /* device arrays holding the state the
+                                          next run starts from (num_inputs) */
+  void* outputs[SODA_HIP_MAX_TENSORS]; /* ... the last run's results
+                                          (num_outputs; for a program that
+                                          iterates these ARE `inputs`) */
+} soda_hip_slab_info_t;
+
+typedef struct soda_hip_group_stats {   /* of the last soda_hip_group_run */
+  int32_t exchange_every;
+  int32_t intervals;                   /* runs of <= exchange_every iterations */
+  int32_t exchanges;                   /* of them opened by a halo exchange */
+  int32_t copies;                      /* peer copies enqueued, all slabs */
+  int64_t copy_bytes;
+  int32_t launches;                    /* kernel launches, all slabs */
+  int32_t split_passes;                /* passes launched in two parts */
+  float enqueue_ms;                    /* host time the run took to enqueue */
+} soda_hip_group_stats_t;
+
+typedef struct soda_hip_group soda_hip_group_t;        /* opaque */
+
+/* Loads the code object on every device of the group and lays out the slabs.
+ * Fails with SODA_HIP_ERR_INVALID if a slab would be thinner than its
+ * neighbour's ghost rows. */
+int soda_hip_group_create(const void* code, size_t code_size,
+                          const soda_hip_plan_t* plan,
+                          const soda_hip_group_desc_t* desc,
+                          soda_hip_group_t** group);
+int soda_hip_group_destroy(soda_hip_group_t* group);
+int soda_hip_group_slab(soda_hip_group_t* group, int32_t slab,
+                        soda_hip_slab_info_t* info);
+/* The exchange interval a group of this description would use (no GPU). */
+int soda_hip_group_plan(const soda_hip_plan_t* plan,
+                        const soda_hip_group_desc_t* desc,
+                        int32_t* exchange_every);
+/* Scatters host arrays (inputs, then one entry per param array of which only
+ * `ptr` is read -- as soda_hip_run_host) over the slabs, ghost rows included:
+ * the state the next run starts from.  Synchronous. */
+int soda_hip_group_load(soda_hip_group_t* group,
+                        const soda_hip_host_tensor_t* inputs);
+/* Tells the group that the caller filled the slabs' `inputs` arrays on the
+ * devices itself (soda_hip_slab_info_t), ghost rows included. */
+int soda_hip_group_loaded(soda_hip_group_t* group);
+/* Advances the state `iterate` iterations.  A program that iterates continues
+ * from the previous run's result (its ghost rows are refreshed first).
+ * Asynchronous: returns when everything is enqueued. */
+int soda_hip_group_run(soda_hip_group_t* group, int32_t iterate);
+int soda_hip_group_synchronize(soda_hip_group_t* group);
+/* Gathers every slab's own rows of the results into host arrays; only box
+ * [valid_lo, valid_hi) of each output is written (NULL: everything), as
+ * soda_hip_run_host_box.  Synchronises first. */
+int soda_hip_group_store(soda_hip_group_t* group,
+                         const soda_hip_host_tensor_t* outputs,
+                         const int32_t* valid_lo, const int32_t* valid_hi);
+/* Replaces soda::app::<app>() on N GPUs: load, run, store. */
+int soda_hip_group_run_host(soda_hip_group_t* group,
+                            const soda_hip_host_tensor_t* inputs,
+                            const soda_hip_host_tensor_t* outputs,
+                            int32_t iterate, const int32_t* valid_lo,
+                            const int32_t* valid_hi);
+int soda_hip_group_last_stats(soda_hip_group_t* group,
+                              soda_hip_group_stats_t* stats);
 
 /* -- the reference kernel's WIRE format: <app>_kernel on banked streams -----
  * The reference's generated host hands its kernel one linear stream per
@@ -381,6 +559,8 @@ int soda_hip_malloc(int32_t device, size_t bytes, void** ptr);
 int soda_hip_free(int32_t device, void* ptr);
 int soda_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int soda_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int soda_hip_memcpy_d2d(void* dst, int32_t dst_device, const void* src,
+                        int32_t src_device, size_t bytes, void* stream);
 int soda_hip_memset(void* dst, int value, size_t bytes, void* stream);
 int soda_hip_stream_synchronize(void* stream);
 int soda_hip_event_create(soda_hip_event_t** event);

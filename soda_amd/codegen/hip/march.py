@@ -677,7 +677,8 @@ class _MarchKernel:
       self.w('  const unsigned bid = blockIdx.x;')
     self.w('  const int tile_x = (int)(bid % (unsigned)a.ntile[0]);')
     if self.dim == 2:
-      self.w('  const int tile_m = (int)(bid / (unsigned)a.ntile[0]);')
+      self.w('  const int tile_l = (int)(bid / (unsigned)a.ntile[0]);')
+      self.w('  const int tile_m = tile_l + (tile_l >= a.skip_from ? a.skip_count : 0);')
       if self.xs:           # the block's waves cover the row side by side
         self.w('  const int strip = wave;')
         self.w('  const int chunk = tile_m;')
@@ -691,8 +692,9 @@ class _MarchKernel:
     else:
       self.w('  const int tile_y = (int)((bid / (unsigned)a.ntile[0]) % '
         '(unsigned)a.ntile[1]);')
-      self.w('  const int chunk = (int)(bid / ((unsigned)a.ntile[0] * '
+      self.w('  const int chunk_l = (int)(bid / ((unsigned)a.ntile[0] * '
         '(unsigned)a.ntile[1]));')
+      self.w('  const int chunk = chunk_l + (chunk_l >= a.skip_from ? a.skip_count : 0);')
       self.w('  const int strip = %s;' % ('wave' if self.xs else 'tile_x'))
       self.w('  const int n0 = a.extent[0], n1 = a.extent[1], nm = a.extent[2];')
       self.w('  const int y0 = tile_y * %d - %d;  // first row held' %

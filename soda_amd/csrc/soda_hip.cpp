@@ -9,22 +9,17 @@
 // fallback of any kind -- without a GPU every run entry fails with
 // SODA_HIP_ERR_NODEVICE.
 //
-// Build: hipcc -O2 -fPIC -shared soda_hip.cpp -o libsoda_hip.so -lhiprtc
-#include "soda_hip.h"
+// Build: hipcc -O2 -fPIC -shared soda_hip.cpp soda_group.cpp -o libsoda_hip.so
+//        -lhiprtc   (__graft_entry__.build_library)
+#include "soda_internal.h"
 
-#include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
-#include <cstdio>
 #include <cstdlib>
-#include <array>
 #include <cstring>
-#include <map>
 #include <new>
-#include <string>
-#include <vector>
 
-namespace {
+namespace soda_detail {
 
 thread_local std::string g_error;
 
@@ -32,6 +27,8 @@ int fail(int status, const std::string& what) {
   g_error = what;
   return status;
 }
+
+const std::string& last_error_text() { return g_error; }
 
 int hip_fail(hipError_t e, const char* what) {
   char buf[512];
@@ -42,17 +39,6 @@ int hip_fail(hipError_t e, const char* what) {
     return SODA_HIP_ERR_NODEVICE;
   return SODA_HIP_ERR_RUNTIME;
 }
-
-#define HIP_TRY(expr)                                   \
-  do {                                                  \
-    hipError_t e_ = (expr);                             \
-    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
-  } while (0)
-
-struct DeviceBuffer {
-  void* ptr = nullptr;
-  size_t bytes = 0;
-};
 
 int ensure(DeviceBuffer& b, size_t bytes) {
   if (b.bytes >= bytes && b.ptr) return SODA_HIP_OK;
@@ -66,28 +52,9 @@ int ensure(DeviceBuffer& b, size_t bytes) {
   return SODA_HIP_OK;
 }
 
-}  // namespace
+}  // namespace soda_detail
 
-struct soda_hip_program {
-  soda_hip_plan_t plan;
-  int device = 0;
-  hipModule_t module = nullptr;
-  std::vector<hipFunction_t> functions;
-  std::vector<DeviceBuffer> locals;   // one per local tensor
-  std::vector<DeviceBuffer> temps;    // one per output: iteration ping-pong
-  std::vector<DeviceBuffer> host_in;  // run_host staging on the device
-  std::vector<DeviceBuffer> host_prm; // ... of the param arrays
-  std::vector<DeviceBuffer> host_out;
-  int32_t last_launches = 0;
-  int32_t last_fused = 0;
-  int64_t last_rows = 0;     // cells along the last dimension, summed over passes
-  void* debug = nullptr;              // time-stamp buffer of diagnostic builds
-  // measured time of one launch of every pass, per extent (calibrate)
-  std::map<std::array<int32_t, SODA_HIP_MAX_DIM>, std::vector<double>> measured;
-  // tile of every kernel on the sub-extents cone-trimmed runs launch on
-  std::map<std::array<int32_t, SODA_HIP_MAX_DIM>,
-           std::vector<std::array<int32_t, SODA_HIP_MAX_DIM>>> sub_tiles;
-};
+using namespace soda_detail;
 
 struct soda_hip_event {
   hipEvent_t ev;
@@ -139,6 +106,11 @@ size_t soda_hip_sizeof(int which) {
     case 3: return sizeof(soda_hip_plan_t);
     case 4: return sizeof(soda_hip_host_tensor_t);
     case 5: return sizeof(soda_hip_stream_desc_t);
+    case 6: return sizeof(soda_hip_slab_run_t);
+    case 7: return sizeof(soda_hip_group_desc_t);
+    case 8: return sizeof(soda_hip_slab_info_t);
+    case 9: return sizeof(soda_hip_group_stats_t);
+    case 10: return sizeof(soda_hip_launch_info_t);
     default: return 0;
   }
 }
@@ -317,6 +289,11 @@ int soda_hip_program_destroy(soda_hip_program_t* p) {
                   &p->host_prm})
     for (auto& b : *v)
       if (b.ptr) (void)hipFree(b.ptr);
+  for (int i = 0; i < 2; ++i) {
+    if (p->ev_pre[i]) (void)hipEventDestroy(p->ev_pre[i]);
+    if (p->ev_bnd[i]) (void)hipEventDestroy(p->ev_bnd[i]);
+  }
+  if (p->side) (void)hipStreamDestroy(p->side);
   if (p->module) (void)hipModuleUnload(p->module);
   delete p;
   return SODA_HIP_OK;
@@ -341,11 +318,6 @@ int waves_per_simd(int vgprs) {
 
 // issue time a wave costs its SIMD, relative to one of >= 3 resident waves
 double issue_share(int64_t k) { return k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0; }
-
-struct Geometry {
-  int32_t tile[SODA_HIP_MAX_DIM];
-  double ns;          // modelled time of one launch; 0: no model
-};
 
 // Length (cells along the marched dimension) one wave should own.  The waves
 // of a launch are dealt evenly over the SIMDs, a SIMD's waves share its issue
@@ -383,7 +355,11 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
   const int k_min = d.warm <= 12 ? 4 : 2;
   double best_cost = 0;
   int32_t best = 0;
-  for (int32_t chunk = n < 8 ? n : 8; chunk <= n; ++chunk) {
+  // Candidates: the cost below grows with the chunk length while the number of
+  // chunks stays the same, so only the shortest chunk of every chunk COUNT can
+  // win -- O(sqrt n) candidates instead of n (a 2M-row stream took 59 ms of
+  // host time per run this way, a launch must not)
+  for (int32_t chunk = n < 8 ? n : 8; chunk <= n;) {
     int64_t chunks = (n + chunk - 1) / chunk;
     int64_t blocks = others * ((chunks + along - 1) / along);
     int64_t waves = blocks * wpb;
@@ -415,6 +391,10 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
       best_cost = cost;
       best = chunk;
     }
+    if (chunks <= 1) break;
+    // the shortest chunk that makes one chunk fewer
+    const int64_t next = (n + chunks - 2) / (chunks - 1);
+    chunk = next > chunk ? (int32_t)next : chunk + 1;
   }
   // latency-bound: more, shorter waves (not for a kernel the registers allow
   // one wave per SIMD of: it has no second wave to hide anything behind)
@@ -540,8 +520,20 @@ int plan_geometry(const soda_hip_plan_t& plan, const int32_t* extent,
 
 }  // namespace
 
-static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
-                  const int32_t* tile, hipStream_t stream) {
+}  // extern "C"
+
+namespace {
+
+// A launch may cover a marching kernel's chunks with a run of them left out
+// (kargs skip_from / skip_count): `count` block tiles along dimension `ax`.
+struct TileRange {
+  int ax;
+  int32_t skip_from, skip_count, count;
+};
+
+int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
+           const int32_t* tile, hipStream_t stream,
+           const TileRange* range = nullptr) {
   const soda_hip_kernel_desc_t& d = p->plan.kernels[k];
   soda_hip_kargs_t args = base;
   int64_t blocks = 1;
@@ -549,8 +541,11 @@ static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
     int32_t t = i < p->plan.dim ? tile[i] : 1;
     args.tile[i] = t;
     args.ntile[i] = (args.extent[i] + t - 1) / t;
+    if (range && range->ax == i) args.ntile[i] = range->count;
     blocks *= args.ntile[i];
   }
+  args.skip_from = range ? range->skip_from : 0;
+  args.skip_count = range ? range->skip_count : 0;
   if (blocks < 1 || blocks > 0x7fffffffLL)
     return fail(SODA_HIP_ERR_INVALID, "grid does not fit a 1-D launch");
   size_t size = sizeof args;
@@ -562,9 +557,15 @@ static int launch(soda_hip_program* p, int k, const soda_hip_kargs_t& base,
   return SODA_HIP_OK;
 }
 
-static int schedule(const soda_hip_plan_t& plan,
-                    const std::vector<double>& pass_ns, int32_t iterate,
-                    int32_t* count, int32_t* total) {
+int64_t ceil_div(int64_t a, int64_t b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+int64_t floor_div(int64_t a, int64_t b) { return a <= 0 ? 0 : a / b; }
+
+}  // namespace
+
+namespace soda_detail {
+
+int schedule(const soda_hip_plan_t& plan, const std::vector<double>& pass_ns,
+             int32_t iterate, int32_t* count, int32_t* total) {
   // modelled times for this extent where every pass has one, else the plan's
   // static relative costs, else greedy
   std::vector<double> cost(plan.num_passes, 0.0);
@@ -611,6 +612,24 @@ static int schedule(const soda_hip_plan_t& plan,
   return SODA_HIP_OK;
 }
 
+int extent_plan(const soda_hip_plan_t& plan,
+                std::map<ExtentKey, ExtentPlan>* cache, const int32_t* ext,
+                const ExtentPlan** out) {
+  ExtentKey key;
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = ext[d];
+  auto it = cache->find(key);
+  if (it == cache->end()) {
+    ExtentPlan ep;
+    if (int rc = plan_geometry(plan, ext, &ep.geo, &ep.model_ns)) return rc;
+    if (cache->size() > 4096) cache->clear();
+    it = cache->emplace(key, std::move(ep)).first;
+  }
+  *out = &it->second;
+  return SODA_HIP_OK;
+}
+
+}  // namespace soda_detail
+
 static int plan_geometry_c(const soda_hip_plan_t* plan, const int32_t* extent,
                            int32_t* tiles, float* pass_ns) {
   if (!plan || !extent) return fail(SODA_HIP_ERR_INVALID, "geometry: NULL argument");
@@ -650,61 +669,113 @@ static int plan_schedule_c(const soda_hip_plan_t* plan, const int32_t* extent,
   return schedule(*plan, ns, iterate, count, &total);
 }
 
-int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
-                        const void* const* inputs, const int32_t* extent,
-                        int32_t iterate, void* stream_) {
-  return soda_hip_run_device_window(p, outputs, inputs, extent, nullptr,
-                                    nullptr, iterate, stream_);
+namespace soda_detail {
+
+// The launches of a run in order: which rows every pass covers (all of them,
+// or the cone that can still reach the kept range) and, next to a halo
+// exchange, how the first and the last pass are cut in two.
+//
+// A pass is launched in two parts when it is ONE marching kernel streaming
+// along the last dimension: the chunks whose inputs include ghost rows still
+// in flight (first pass of the run) or whose rows the neighbours fetch next
+// (last pass) form the boundary [0, bnd_lo) U [bnd_hi, chunks), the rest the
+// interior.  Any other pass waits, runs whole, and signals.
+int plan_launches(const soda_hip_plan_t& plan,
+                  std::map<ExtentKey, ExtentPlan>* cache, const int32_t* ext,
+                  const int32_t* count, int32_t total, int32_t iterate,
+                  const SlabRun* slab, std::vector<PassLaunch>* out) {
+  const int ax = plan.dim - 1;
+  const int32_t rows = ext[ax];
+  const Cone* cone = slab ? &slab->cone : nullptr;
+  out->clear();
+  out->reserve(total);
+  int done = 0, done_iters = 0;
+  for (int i = 0; i < plan.num_passes; ++i) {
+    for (int c = 0; c < count[i]; ++c, ++done) {
+      PassLaunch L;
+      memset(&L, 0, sizeof L);
+      L.pass = i;
+      // Rows this pass has to touch.  With a cone: the rows it must DELIVER
+      // are those the iterations still to come can carry into the kept range;
+      // it is launched on these plus the rows its own iterations read beyond
+      // them (their results are written too, and are wrong where the launch
+      // saw zeros instead of neighbours -- nothing reads them again).
+      int32_t lo = 0, hi = rows;
+      const int32_t fused = plan.passes[i].fused_iters;
+      done_iters += fused;
+      if (cone) {
+        const int64_t after = iterate - done_iters;        // iterations to come
+        const int64_t a = cone->keep_lo - (after + fused) * (int64_t)cone->reach_lo;
+        const int64_t b = cone->keep_hi + (after + fused) * (int64_t)cone->reach_hi;
+        if (cone->keep_lo > 0 && a > 0) lo = (int32_t)a;
+        if (cone->keep_hi < rows && b < rows) hi = (int32_t)b;
+      }
+      L.lo = lo;
+      L.hi = hi;
+      const bool first = done == 0, last = done + 1 == total;
+      L.wait = first && slab && slab->ghosts_ready;
+      L.record = last && slab && slab->sendable;
+      const int k0 = plan.passes[i].kernel[0];
+      if ((L.wait || L.record) && plan.passes[i].num_kernels == 1 &&
+          plan.kernels[k0].march_dim == plan.dim) {
+        int32_t sub[SODA_HIP_MAX_DIM];
+        for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) sub[d] = ext[d];
+        sub[ax] = hi - lo;
+        const ExtentPlan* use = nullptr;
+        if (int rc = extent_plan(plan, cache, sub, &use)) return rc;
+        const int64_t lb = use->geo[k0].tile[ax];
+        const int64_t nchunk = (hi - lo + lb - 1) / lb;
+        int64_t bnd_lo = 0, bnd_hi = nchunk;
+        if (L.wait) {
+          // chunk c reads rows [c lb - fused reach_lo, (c + 1) lb + fused reach_hi)
+          if (slab->ghost_lo > 0)
+            bnd_lo = ceil_div(slab->ghost_lo - lo + (int64_t)fused * cone->reach_lo, lb);
+          if (slab->ghost_hi > 0)
+            bnd_hi = floor_div(rows - slab->ghost_hi - lo -
+                               (int64_t)fused * cone->reach_hi, lb);
+        }
+        if (L.record) {
+          // chunks that deliver send rows -- and, below / above them, the only
+          // ones that write the result's ghost rows
+          if (slab->send_lo > 0) {
+            const int64_t v = ceil_div(cone->keep_lo + slab->send_lo - lo, lb);
+            if (v > bnd_lo) bnd_lo = v;
+          }
+          if (slab->send_hi > 0) {
+            const int64_t v = floor_div(cone->keep_hi - slab->send_hi - lo, lb);
+            if (v < bnd_hi) bnd_hi = v;
+          }
+        }
+        if (bnd_lo > nchunk) bnd_lo = nchunk;
+        if (bnd_hi > nchunk) bnd_hi = nchunk;
+        L.chunk = (int32_t)lb;
+        L.chunks = (int32_t)nchunk;
+        L.bnd_lo = (int32_t)bnd_lo;
+        L.bnd_hi = (int32_t)bnd_hi;
+        L.split = bnd_lo < bnd_hi && (bnd_lo > 0 || bnd_hi < nchunk);
+      }
+      out->push_back(L);
+    }
+  }
+  return SODA_HIP_OK;
 }
 
-// rows (cells along the last dimension) a run must deliver, and how far one
-// iteration reaches beyond a row on either side: passes may then skip the rows
-// whose results no later iteration of the run can carry into [keep_lo, keep_hi)
-struct Cone {
-  int32_t keep_lo, keep_hi, reach_lo, reach_hi;
-};
-
-static int run_core(soda_hip_program_t* p, void* const* outputs,
-                    const void* const* inputs, const int32_t* extent,
-                    const int32_t* origin, const int32_t* global_extent,
-                    int32_t iterate, void* stream_, int force_pass,
-                    const Cone* cone = nullptr);
-
-int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
-                               const void* const* inputs,
-                               const int32_t* extent, const int32_t* origin,
-                               const int32_t* global_extent, int32_t iterate,
-                               void* stream_) {
-  return run_core(p, outputs, inputs, extent, origin, global_extent, iterate,
-                  stream_, -1);
+// the stream and events of split passes, made on first use
+static int side_stream(soda_hip_program* p) {
+  if (p->side) return SODA_HIP_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_pre[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_bnd[i], hipEventDisableTiming));
+  }
+  return SODA_HIP_OK;
 }
 
-int soda_hip_run_device_cone(soda_hip_program_t* p, void* const* outputs,
-                             const void* const* inputs, const int32_t* extent,
-                             const int32_t* origin,
-                             const int32_t* global_extent, int32_t iterate,
-                             int32_t keep_lo, int32_t keep_hi,
-                             int32_t reach_lo, int32_t reach_hi,
-                             void* stream_) {
-  if (!p || !extent)
-    return fail(SODA_HIP_ERR_INVALID, "run_device_cone: NULL argument");
-  const int ax = p->plan.dim - 1;
-  if (keep_lo < 0 || keep_hi > extent[ax] || keep_lo >= keep_hi ||
-      reach_lo < 0 || reach_hi < 0)
-    return fail(SODA_HIP_ERR_INVALID,
-                "run_device_cone: [keep_lo, keep_hi) must be a non-empty range "
-                "of the last dimension, the reaches non-negative");
-  const Cone cone = {keep_lo, keep_hi, reach_lo, reach_hi};
-  return run_core(p, outputs, inputs, extent, origin, global_extent, iterate,
-                  stream_, -1, &cone);
-}
-
-// force_pass >= 0: use only that pass (calibration)
-static int run_core(soda_hip_program_t* p, void* const* outputs,
-                    const void* const* inputs, const int32_t* extent,
-                    const int32_t* origin, const int32_t* global_extent,
-                    int32_t iterate, void* stream_, int force_pass,
-                    const Cone* cone) {
+int run_core(soda_hip_program_t* p, void* const* outputs,
+             const void* const* inputs, const int32_t* extent,
+             const int32_t* origin, const int32_t* global_extent,
+             int32_t iterate, void* stream_, int force_pass,
+             const SlabRun* slab) {
   if (!p || !outputs || !inputs || !extent)
     return fail(SODA_HIP_ERR_INVALID, "run_device: NULL argument");
   const soda_hip_plan_t& plan = p->plan;
@@ -715,6 +786,7 @@ static int run_core(soda_hip_program_t* p, void* const* outputs,
                 "iterate > 1 times");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIP_TRY(hipSetDevice(p->device));
+  const Cone* cone = slab ? &slab->cone : nullptr;
 
   soda_hip_kargs_t base;
   memset(&base, 0, sizeof base);
@@ -745,10 +817,9 @@ static int run_core(soda_hip_program_t* p, void* const* outputs,
   // schedule: the multiset of passes that adds up to `iterate` at least total
   // cost (100 iterations with passes of 12 / 8 / 4 / 1: 7 x 12 + 2 x 8 beats
   // 8 x 12 + 4); without costs, as many of the deepest kind as fit, then the
-  // next...
-  std::vector<Geometry> geo;
-  std::vector<double> pass_ns;
-  if (int rc = plan_geometry(plan, base.extent, &geo, &pass_ns)) return rc;
+  // next...  Remembered per (extent, iterate).
+  const ExtentPlan* ep = nullptr;
+  if (int rc = extent_plan(plan, &p->extents, base.extent, &ep)) return rc;
   int32_t count[SODA_HIP_MAX_PASSES];
   int32_t total = 0;
   if (force_pass >= 0) {
@@ -758,13 +829,24 @@ static int run_core(soda_hip_program_t* p, void* const* outputs,
     for (int i = 0; i < plan.num_passes; ++i) count[i] = 0;
     count[force_pass] = total = iterate / plan.passes[force_pass].fused_iters;
   } else {
-    // measured launch times of this very extent (soda_hip_program_calibrate)
-    // outrank the model
-    std::array<int32_t, SODA_HIP_MAX_DIM> key;
-    for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = base.extent[d];
-    auto it = p->measured.find(key);
-    if (it != p->measured.end()) pass_ns = it->second;
-    if (int rc = schedule(plan, pass_ns, iterate, count, &total)) return rc;
+    auto& memo = const_cast<ExtentPlan*>(ep)->sched;
+    auto hit = memo.find(iterate);
+    if (hit == memo.end()) {
+      // measured launch times of this very extent (soda_hip_program_calibrate)
+      // outrank the model
+      ExtentKey key;
+      for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = base.extent[d];
+      auto it = p->measured.find(key);
+      const std::vector<double>& pass_ns =
+          it != p->measured.end() ? it->second : ep->model_ns;
+      if (int rc = schedule(plan, pass_ns, iterate, count, &total)) return rc;
+      std::vector<int32_t> row(count, count + plan.num_passes);
+      row.push_back(total);
+      if (memo.size() > 256) memo.clear();
+      hit = memo.emplace(iterate, std::move(row)).first;
+    }
+    for (int i = 0; i < plan.num_passes; ++i) count[i] = hit->second[i];
+    total = hit->second[plan.num_passes];
   }
 
   if (p->debug) base.buf[SODA_HIP_MAX_TENSORS - 1] = p->debug;
@@ -790,77 +872,186 @@ static int run_core(soda_hip_program_t* p, void* const* outputs,
       if (rc) return rc;
     }
 
+  std::vector<PassLaunch> launches;
+  if (int rc = plan_launches(plan, &p->extents, base.extent, count, total,
+                             iterate, slab, &launches))
+    return rc;
   p->last_launches = 0;
   p->last_fused = 0;
+  p->last_split = 0;
   p->last_rows = 0;
   std::vector<const void*> src(inputs, inputs + plan.num_inputs);
   const int ax = plan.dim - 1;
   const int32_t rows = base.extent[ax];
-  int done = 0, done_iters = 0;
-  for (int i = 0; i < plan.num_passes; ++i) {
-    for (int c = 0; c < count[i]; ++c, ++done) {
-      // the last pass writes the caller's outputs; before that alternate
-      // between the program's temporaries and the caller's outputs
-      bool to_out = ((total - 1 - done) % 2) == 0;
-      for (int j = 0; j < plan.num_inputs; ++j)
-        base.buf[in0 + j] = const_cast<void*>(src[j]);
-      for (int o = 0; o < plan.num_outputs; ++o)
-        base.buf[out0 + o] = to_out ? outputs[o] : p->temps[o].ptr;
-      // Rows this pass has to touch.  With a cone: the rows it must DELIVER
-      // are those the iterations still to come can carry into the kept range;
-      // it is launched on these plus the rows its own iterations read beyond
-      // them (their results are written too, and are wrong where the launch
-      // saw zeros instead of neighbours -- nothing reads them again).
-      int32_t lo = 0, hi = rows;
-      const int32_t fused = plan.passes[i].fused_iters;
-      done_iters += fused;
-      if (cone) {
-        const int64_t after = iterate - done_iters;        // iterations to come
-        const int64_t a = cone->keep_lo - (after + fused) * (int64_t)cone->reach_lo;
-        const int64_t b = cone->keep_hi + (after + fused) * (int64_t)cone->reach_hi;
-        if (cone->keep_lo > 0 && a > 0) lo = (int32_t)a;
-        if (cone->keep_hi < rows && b < rows) hi = (int32_t)b;
-      }
-      soda_hip_kargs_t args = base;
-      const std::vector<std::array<int32_t, SODA_HIP_MAX_DIM>>* sub = nullptr;
-      if (lo > 0 || hi < rows) {
-        args.extent[ax] = hi - lo;
-        args.origin[ax] = base.origin[ax] + lo;
-        for (int t = 0; t < plan.num_inputs + plan.num_outputs; ++t)
-          args.buf[t] = static_cast<char*>(base.buf[t]) +
-                        (int64_t)lo * base.stride[ax] * plan.elem_size[t];
-        // (remembered per extent: sizing the chunks of every kernel costs
-        // tens of microseconds of host time, a launch must not)
-        std::array<int32_t, SODA_HIP_MAX_DIM> key;
-        for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = args.extent[d];
-        auto it = p->sub_tiles.find(key);
-        if (it == p->sub_tiles.end()) {
-          std::vector<Geometry> sub_geo;
-          std::vector<double> unused;
-          if (int rc = plan_geometry(plan, args.extent, &sub_geo, &unused))
-            return rc;
-          std::vector<std::array<int32_t, SODA_HIP_MAX_DIM>> tiles(sub_geo.size());
-          for (size_t k = 0; k < sub_geo.size(); ++k)
-            for (int d = 0; d < SODA_HIP_MAX_DIM; ++d)
-              tiles[k][d] = sub_geo[k].tile[d];
-          if (p->sub_tiles.size() > 4096) p->sub_tiles.clear();
-          it = p->sub_tiles.emplace(key, std::move(tiles)).first;
-        }
-        sub = &it->second;
-      }
-      p->last_rows += hi - lo;
+  for (size_t done = 0; done < launches.size(); ++done) {
+    const PassLaunch& L = launches[done];
+    const int i = L.pass;
+    // the last pass writes the caller's outputs; before that alternate
+    // between the program's temporaries and the caller's outputs
+    bool to_out = ((total - 1 - (int)done) % 2) == 0;
+    for (int j = 0; j < plan.num_inputs; ++j)
+      base.buf[in0 + j] = const_cast<void*>(src[j]);
+    for (int o = 0; o < plan.num_outputs; ++o)
+      base.buf[out0 + o] = to_out ? outputs[o] : p->temps[o].ptr;
+    soda_hip_kargs_t args = base;
+    if (L.lo > 0 || L.hi < rows) {
+      args.extent[ax] = L.hi - L.lo;
+      args.origin[ax] = base.origin[ax] + L.lo;
+      for (int t = 0; t < plan.num_inputs + plan.num_outputs; ++t)
+        args.buf[t] = static_cast<char*>(base.buf[t]) +
+                      (int64_t)L.lo * base.stride[ax] * plan.elem_size[t];
+    }
+    const ExtentPlan* use = nullptr;
+    if (int rc = extent_plan(plan, &p->extents, args.extent, &use)) return rc;
+    p->last_rows += L.hi - L.lo;
+    const int k0 = plan.passes[i].kernel[0];
+    if (L.split) {
+      // the boundary chunks on the program's side stream, the interior on the
+      // caller's: the two share the GPU, the copies run underneath
+      if (int rc = side_stream(p)) return rc;
+      const int turn = p->ev_turn;
+      p->ev_turn ^= 1;
+      HIP_TRY(hipEventRecord(p->ev_pre[turn], stream));
+      HIP_TRY(hipStreamWaitEvent(p->side, p->ev_pre[turn], 0));
+      if (L.wait) HIP_TRY(hipStreamWaitEvent(p->side, slab->ghosts_ready, 0));
+      const int32_t hole = L.bnd_hi - L.bnd_lo;
+      const TileRange boundary = {ax, L.bnd_lo, hole, L.chunks - hole};
+      if (int rc = launch(p, k0, args, use->geo[k0].tile, p->side, &boundary))
+        return rc;
+      if (L.record) HIP_TRY(hipEventRecord(slab->sendable, p->side));
+      HIP_TRY(hipEventRecord(p->ev_bnd[turn], p->side));
+      const TileRange interior = {ax, 0, L.bnd_lo, hole};
+      if (int rc = launch(p, k0, args, use->geo[k0].tile, stream, &interior))
+        return rc;
+      HIP_TRY(hipStreamWaitEvent(stream, p->ev_bnd[turn], 0));
+      p->last_launches += 2;
+      if (i == 0) ++p->last_fused;
+      ++p->last_split;
+    } else {
+      if (L.wait) HIP_TRY(hipStreamWaitEvent(stream, slab->ghosts_ready, 0));
       for (int k = 0; k < plan.passes[i].num_kernels; ++k) {
         const int kk = plan.passes[i].kernel[k];
-        int rc = launch(p, kk, args,
-                        sub ? (*sub)[kk].data() : geo[kk].tile, stream);
+        int rc = launch(p, kk, args, use->geo[kk].tile, stream);
         if (rc) return rc;
         ++p->last_launches;
         if (i == 0) ++p->last_fused;
       }
-      if (done + 1 < total)
-        for (int j = 0; j < plan.num_inputs; ++j) src[j] = base.buf[out0 + j];
+      if (L.record) HIP_TRY(hipEventRecord(slab->sendable, stream));
     }
+    if ((int)done + 1 < total)
+      for (int j = 0; j < plan.num_inputs; ++j) src[j] = base.buf[out0 + j];
   }
+  return SODA_HIP_OK;
+}
+
+}  // namespace soda_detail
+
+extern "C" {
+
+int soda_hip_run_device(soda_hip_program_t* p, void* const* outputs,
+                        const void* const* inputs, const int32_t* extent,
+                        int32_t iterate, void* stream_) {
+  return run_core(p, outputs, inputs, extent, nullptr, nullptr, iterate,
+                  stream_, -1, nullptr);
+}
+
+int soda_hip_run_device_window(soda_hip_program_t* p, void* const* outputs,
+                               const void* const* inputs,
+                               const int32_t* extent, const int32_t* origin,
+                               const int32_t* global_extent, int32_t iterate,
+                               void* stream_) {
+  return run_core(p, outputs, inputs, extent, origin, global_extent, iterate,
+                  stream_, -1, nullptr);
+}
+
+int soda_hip_run_device_cone(soda_hip_program_t* p, void* const* outputs,
+                             const void* const* inputs, const int32_t* extent,
+                             const int32_t* origin,
+                             const int32_t* global_extent, int32_t iterate,
+                             int32_t keep_lo, int32_t keep_hi,
+                             int32_t reach_lo, int32_t reach_hi,
+                             void* stream_) {
+  soda_hip_slab_run_t run;
+  memset(&run, 0, sizeof run);
+  run.keep_lo = keep_lo;
+  run.keep_hi = keep_hi;
+  run.reach_lo = reach_lo;
+  run.reach_hi = reach_hi;
+  return soda_hip_run_device_slab(p, outputs, inputs, extent, origin,
+                                  global_extent, iterate, &run, stream_);
+}
+
+static int slab_run(const soda_hip_slab_run_t* run, const int32_t* extent,
+                    int ax, SlabRun* out);
+
+int soda_hip_run_device_slab(soda_hip_program_t* p, void* const* outputs,
+                             const void* const* inputs, const int32_t* extent,
+                             const int32_t* origin,
+                             const int32_t* global_extent, int32_t iterate,
+                             const soda_hip_slab_run_t* run, void* stream_) {
+  if (!p || !extent || !run)
+    return fail(SODA_HIP_ERR_INVALID, "run_device_slab: NULL argument");
+  SlabRun s;
+  if (int rc = slab_run(run, extent, p->plan.dim - 1, &s)) return rc;
+  return run_core(p, outputs, inputs, extent, origin, global_extent, iterate,
+                  stream_, -1, &s);
+}
+
+int soda_hip_plan_launches(const soda_hip_plan_t* plan, const int32_t* extent,
+                           int32_t iterate, const soda_hip_slab_run_t* run,
+                           int32_t capacity, soda_hip_launch_info_t* launches,
+                           int32_t* count) {
+  if (!plan || !extent || !count || capacity < 0 || (capacity && !launches))
+    return fail(SODA_HIP_ERR_INVALID, "plan_launches: bad argument");
+  if (iterate < 1) return fail(SODA_HIP_ERR_INVALID, "cannot iterate < 1 times");
+  if (int rc = check_plan(plan)) return rc;
+  int32_t ext[SODA_HIP_MAX_DIM];
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+    ext[d] = d < plan->dim ? extent[d] : 1;
+    if (ext[d] < 1) return fail(SODA_HIP_ERR_INVALID, "plan_launches: extent < 1");
+  }
+  SlabRun s;
+  if (run)
+    if (int rc = slab_run(run, ext, plan->dim - 1, &s)) return rc;
+  std::map<ExtentKey, ExtentPlan> cache;
+  const ExtentPlan* ep = nullptr;
+  if (int rc = extent_plan(*plan, &cache, ext, &ep)) return rc;
+  int32_t per_pass[SODA_HIP_MAX_PASSES], total = 0;
+  if (int rc = schedule(*plan, ep->model_ns, iterate, per_pass, &total)) return rc;
+  std::vector<PassLaunch> list;
+  if (int rc = plan_launches(*plan, &cache, ext, per_pass, total, iterate,
+                             run ? &s : nullptr, &list))
+    return rc;
+  *count = (int32_t)list.size();
+  for (int32_t i = 0; i < *count && i < capacity; ++i) {
+    const PassLaunch& L = list[i];
+    launches[i] = {plan->passes[L.pass].fused_iters, L.lo, L.hi, L.wait,
+                   L.record, L.split, L.chunk, L.chunks, L.bnd_lo, L.bnd_hi};
+  }
+  return SODA_HIP_OK;
+}
+
+static int slab_run(const soda_hip_slab_run_t* run, const int32_t* extent,
+                    int ax, SlabRun* out) {
+  if (run->keep_lo < 0 || run->keep_hi > extent[ax] ||
+      run->keep_lo >= run->keep_hi || run->reach_lo < 0 || run->reach_hi < 0)
+    return fail(SODA_HIP_ERR_INVALID,
+                "run_device_slab: [keep_lo, keep_hi) must be a non-empty range "
+                "of the last dimension, the reaches non-negative");
+  if (run->ghost_lo < 0 || run->ghost_hi < 0 || run->send_lo < 0 ||
+      run->send_hi < 0 || run->ghost_lo + run->ghost_hi > extent[ax] ||
+      run->send_lo > run->keep_hi - run->keep_lo ||
+      run->send_hi > run->keep_hi - run->keep_lo)
+    return fail(SODA_HIP_ERR_INVALID,
+                "run_device_slab: ghost / send rows out of range");
+  SlabRun& s = *out;
+  s.cone = {run->keep_lo, run->keep_hi, run->reach_lo, run->reach_hi};
+  s.ghost_lo = run->ghost_lo;
+  s.ghost_hi = run->ghost_hi;
+  s.send_lo = run->send_lo;
+  s.send_hi = run->send_hi;
+  s.ghosts_ready = static_cast<hipEvent_t>(run->ghosts_ready);
+  s.sendable = static_cast<hipEvent_t>(run->sendable);
   return SODA_HIP_OK;
 }
 
@@ -880,6 +1071,8 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
   }
   if (plan.num_passes < 2 || plan.num_inputs != plan.num_outputs) {
     p->measured.erase(key);          // nothing to choose between
+    auto it = p->extents.find(key);
+    if (it != p->extents.end()) it->second.sched.clear();
     return SODA_HIP_OK;
   }
   // stand-in arrays: inputs (a byte pattern that reads as ~0.75 in fp32, small
@@ -923,15 +1116,16 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
     for (int round = 0; round < 2 && rc == SODA_HIP_OK; ++round)
       for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i)
         rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
-                      plan.passes[i].fused_iters * launches, stream_, i);
+                      plan.passes[i].fused_iters * launches, stream_, i,
+                      nullptr);
     for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
       const int32_t iters = plan.passes[i].fused_iters * launches;
       rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
-                    iters, stream_, i);
+                    iters, stream_, i, nullptr);
       if (rc != SODA_HIP_OK) break;
       (void)hipEventRecord(ev[2 * i], stream);
       rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
-                    iters, stream_, i);
+                    iters, stream_, i, nullptr);
       (void)hipEventRecord(ev[2 * i + 1], stream);
     }
     if (rc == SODA_HIP_OK && hipStreamSynchronize(stream) != hipSuccess)
@@ -947,7 +1141,11 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
     if (e) (void)hipEventDestroy(e);
   for (auto& b : bufs)
     if (b.ptr) (void)hipFree(b.ptr);
-  if (rc == SODA_HIP_OK) p->measured[key] = ns;
+  if (rc == SODA_HIP_OK) {
+    p->measured[key] = ns;
+    auto it = p->extents.find(key);        // schedules made from the model
+    if (it != p->extents.end()) it->second.sched.clear();
+  }
   return rc;
 }
 
@@ -994,6 +1192,12 @@ int soda_hip_last_launches(soda_hip_program_t* p, int32_t* launches,
   return SODA_HIP_OK;
 }
 
+int soda_hip_last_split(soda_hip_program_t* p, int32_t* passes) {
+  if (!p || !passes) return fail(SODA_HIP_ERR_INVALID, "NULL argument");
+  *passes = p->last_split;
+  return SODA_HIP_OK;
+}
+
 int soda_hip_last_rows(soda_hip_program_t* p, int64_t* rows) {
   if (!p || !rows) return fail(SODA_HIP_ERR_INVALID, "NULL argument");
   *rows = p->last_rows;
@@ -1002,7 +1206,11 @@ int soda_hip_last_rows(soda_hip_program_t* p, int64_t* rows) {
 
 // -- host-array entry (soda::app::<app> analogue) ----------------------------
 
-static bool is_dense(const soda_hip_host_tensor_t& t, int dim) {
+}  // extern "C"
+
+namespace soda_detail {
+
+bool is_dense(const soda_hip_host_tensor_t& t, int dim) {
   int64_t s = 1;
   for (int d = 0; d < dim; ++d) {
     if (t.stride[d] != s) return false;
@@ -1012,9 +1220,9 @@ static bool is_dense(const soda_hip_host_tensor_t& t, int dim) {
 }
 
 // copies box [lo, hi) between a strided host array and a dense staging array
-static void copy_box(char* strided, const int32_t* stride, char* dense,
-                     const int32_t* extent, const int32_t* lo,
-                     const int32_t* hi, int dim, int elem, bool to_dense) {
+void copy_box(char* strided, const int32_t* stride, char* dense,
+              const int32_t* extent, const int32_t* lo, const int32_t* hi,
+              int dim, int elem, bool to_dense) {
   int32_t idx[SODA_HIP_MAX_DIM];
   int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
   int64_t dstride[SODA_HIP_MAX_DIM], s = 1;
@@ -1048,6 +1256,10 @@ static void copy_box(char* strided, const int32_t* stride, char* dense,
         }
       }
 }
+
+}  // namespace soda_detail
+
+extern "C" {
 
 int soda_hip_run_host_box(soda_hip_program_t* p,
                           const soda_hip_host_tensor_t* inputs,
@@ -1380,6 +1592,17 @@ int soda_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) 
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost,
                          static_cast<hipStream_t>(stream)));
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return SODA_HIP_OK;
+}
+
+int soda_hip_memcpy_d2d(void* dst, int32_t dst_device, const void* src,
+                        int32_t src_device, size_t bytes, void* stream) {
+  if (dst_device == src_device)
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+  else
+    HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes,
+                               static_cast<hipStream_t>(stream)));
   return SODA_HIP_OK;
 }
 

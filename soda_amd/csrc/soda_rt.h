@@ -36,6 +36,9 @@ struct soda_hip_kargs_t {
   int32_t tile[4];
   int32_t origin[4];
   int32_t gextent[4];
+  int32_t skip_from;     // block tile t along a marching kernel's streamed
+  int32_t skip_count;    // dimension stands for t + (t >= skip_from ? skip_count : 0)
+  int32_t reserved[2];
 };
 
 #define SODA_DEV static __device__ inline __attribute__((always_inline))

@@ -38,8 +38,11 @@ MAX_KERNELS = 32
 MAX_PASSES = 8
 MAX_PASS_KERNELS = 16
 MAX_PARAMS = 8
+MAX_SLABS = 64
 NAME_LEN = 96
-ABI_VERSION = 5
+GROUP_NO_OVERLAP = 1
+GROUP_CALIBRATE = 2
+ABI_VERSION = 6
 
 
 class KernelDesc(ctypes.Structure):
@@ -97,6 +100,54 @@ class StreamDesc(ctypes.Structure):
               ('linear_vec', ctypes.c_int32 * 4)]
 
 
+class SlabRun(ctypes.Structure):
+  """Mirror of soda_hip_slab_run_t: a run between two halo exchanges."""
+  _fields_ = [('keep_lo', ctypes.c_int32), ('keep_hi', ctypes.c_int32),
+              ('reach_lo', ctypes.c_int32), ('reach_hi', ctypes.c_int32),
+              ('ghost_lo', ctypes.c_int32), ('ghost_hi', ctypes.c_int32),
+              ('send_lo', ctypes.c_int32), ('send_hi', ctypes.c_int32),
+              ('ghosts_ready', ctypes.c_void_p),
+              ('sendable', ctypes.c_void_p)]
+
+
+class LaunchInfo(ctypes.Structure):
+  """Mirror of soda_hip_launch_info_t."""
+  _fields_ = [(n, ctypes.c_int32) for n in (
+      'fused_iters', 'lo', 'hi', 'wait', 'record', 'split', 'chunk', 'chunks',
+      'bnd_lo', 'bnd_hi')]
+
+
+class GroupDesc(ctypes.Structure):
+  """Mirror of soda_hip_group_desc_t."""
+  _fields_ = [('num_slabs', ctypes.c_int32),
+              ('device', ctypes.c_int32 * MAX_SLABS),
+              ('extent', ctypes.c_int32 * MAX_DIM),
+              ('reach_lo', ctypes.c_int32), ('reach_hi', ctypes.c_int32),
+              ('iterate', ctypes.c_int32),
+              ('exchange_every', ctypes.c_int32),
+              ('flags', ctypes.c_int32)]
+
+
+class SlabInfo(ctypes.Structure):
+  """Mirror of soda_hip_slab_info_t."""
+  _fields_ = [('device', ctypes.c_int32),
+              ('begin', ctypes.c_int32), ('end', ctypes.c_int32),
+              ('own_begin', ctypes.c_int32), ('own_end', ctypes.c_int32),
+              ('ghost_lo', ctypes.c_int32), ('ghost_hi', ctypes.c_int32),
+              ('extent', ctypes.c_int32 * MAX_DIM),
+              ('inputs', ctypes.c_void_p * MAX_TENSORS),
+              ('outputs', ctypes.c_void_p * MAX_TENSORS)]
+
+
+class GroupStats(ctypes.Structure):
+  """Mirror of soda_hip_group_stats_t."""
+  _fields_ = [('exchange_every', ctypes.c_int32),
+              ('intervals', ctypes.c_int32), ('exchanges', ctypes.c_int32),
+              ('copies', ctypes.c_int32), ('copy_bytes', ctypes.c_int64),
+              ('launches', ctypes.c_int32), ('split_passes', ctypes.c_int32),
+              ('enqueue_ms', ctypes.c_float)]
+
+
 class HostTensor(ctypes.Structure):
   _fields_ = [('ptr', ctypes.c_void_p),
               ('extent', ctypes.POINTER(ctypes.c_int32)),
@@ -136,7 +187,40 @@ API = {
     'soda_hip_run_device_cone': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _pi32,
                                                 _pi32, _i32, _i32, _i32, _i32,
                                                 _i32, _vp]),
+    'soda_hip_run_device_slab': (ctypes.c_int, [_vp, _pvp, _pvp, _pi32, _pi32,
+                                                _pi32, _i32,
+                                                ctypes.POINTER(SlabRun), _vp]),
+    'soda_hip_plan_launches': (ctypes.c_int, [
+        ctypes.POINTER(Plan), _pi32, _i32, ctypes.POINTER(SlabRun), _i32,
+        ctypes.POINTER(LaunchInfo), _pi32
+    ]),
     'soda_hip_last_rows': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    'soda_hip_last_split': (ctypes.c_int, [_vp, _pi32]),
+    'soda_hip_group_create': (ctypes.c_int, [
+        _vp, ctypes.c_size_t, ctypes.POINTER(Plan), ctypes.POINTER(GroupDesc),
+        _pvp
+    ]),
+    'soda_hip_group_destroy': (ctypes.c_int, [_vp]),
+    'soda_hip_group_slab': (ctypes.c_int, [_vp, _i32,
+                                           ctypes.POINTER(SlabInfo)]),
+    'soda_hip_group_plan': (ctypes.c_int, [
+        ctypes.POINTER(Plan), ctypes.POINTER(GroupDesc), _pi32
+    ]),
+    'soda_hip_group_load': (ctypes.c_int, [_vp, ctypes.POINTER(HostTensor)]),
+    'soda_hip_group_loaded': (ctypes.c_int, [_vp]),
+    'soda_hip_group_run': (ctypes.c_int, [_vp, _i32]),
+    'soda_hip_group_synchronize': (ctypes.c_int, [_vp]),
+    'soda_hip_group_store': (ctypes.c_int, [_vp, ctypes.POINTER(HostTensor),
+                                            _pi32, _pi32]),
+    'soda_hip_group_run_host': (ctypes.c_int, [
+        _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32,
+        _pi32, _pi32
+    ]),
+    'soda_hip_group_last_stats': (ctypes.c_int, [
+        _vp, ctypes.POINTER(GroupStats)
+    ]),
+    'soda_hip_memcpy_d2d': (ctypes.c_int, [_vp, _i32, _vp, _i32,
+                                           ctypes.c_size_t, _vp]),
     'soda_hip_run_host': (ctypes.c_int, [
         _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32
     ]),
@@ -204,7 +288,9 @@ def library() -> ctypes.CDLL:
       raise util.BackendError('libsoda_hip.so has ABI version %d, expected %d' %
                               (lib.soda_hip_abi_version(), ABI_VERSION))
     for which, mirror in ((1, KernelDesc), (2, PassDesc), (3, Plan),
-                          (4, HostTensor), (5, StreamDesc)):
+                          (4, HostTensor), (5, StreamDesc), (6, SlabRun),
+                          (7, GroupDesc), (8, SlabInfo), (9, GroupStats),
+                          (10, LaunchInfo)):
       if lib.soda_hip_sizeof(which) != ctypes.sizeof(mirror):
         raise util.BackendError(
             'struct layout mismatch between libsoda_hip.so and runtime.py '
@@ -453,6 +539,23 @@ def plan_schedule(plan: Plan, extent: Sequence[int], iterate: int):
   return list(count)
 
 
+def plan_launches(plan: Plan, extent: Sequence[int], iterate: int,
+                  run: Optional[SlabRun] = None):
+  """The launches a run on `extent` would issue (soda_hip_plan_launches): a
+  list of dicts, one per launch, in order.  No GPU needed."""
+  lib = library()
+  ext = (ctypes.c_int32 * MAX_DIM)(*(list(extent) + [1] * (MAX_DIM - len(extent))))
+  n = ctypes.c_int32(0)
+  cap = 4096
+  arr = (LaunchInfo * cap)()
+  check(lib.soda_hip_plan_launches(ctypes.byref(plan), ext, iterate,
+                                   ctypes.byref(run) if run is not None else
+                                   None, cap, arr, ctypes.byref(n)),
+        'launches of %d iterations' % iterate)
+  return [{name: getattr(arr[i], name) for name, _ in LaunchInfo._fields_}
+          for i in range(min(n.value, cap))]
+
+
 def pick_vec(stencil: core.Stencil, extent: Optional[Sequence[int]]) -> int:
   """Cells per lane per row: 16 bytes' worth, reduced until it divides the
   row length (rows must stay 16-byte aligned for the vector loads)."""
@@ -684,7 +787,10 @@ class Program:
                  extent: Sequence[int], iterate: Optional[int] = None,
                  stream: int = 0, origin: Optional[Sequence[int]] = None,
                  global_extent: Optional[Sequence[int]] = None,
-                 keep: Optional[Sequence[int]] = None) -> None:
+                 keep: Optional[Sequence[int]] = None,
+                 ghosts: Optional[Sequence[int]] = None,
+                 sends: Optional[Sequence[int]] = None,
+                 ghosts_ready: int = 0, sendable: int = 0) -> None:
     """`outputs` / `inputs` are device addresses (e.g. tensor.data_ptr()) of
     dense dim-0-fastest arrays; asynchronous on `stream`.  `inputs` holds the
     input tensors followed by the program's `param` arrays (C order).  For a
@@ -692,7 +798,17 @@ class Program:
     the whole grid (`global_extent`): `border: preserve` means the GLOBAL border.
     `keep` = (lo, hi): only cells [lo, hi) along the last dimension of the
     result are needed (a slab's own rows); passes then skip the rows nothing
-    can carry into that range any more (soda_hip_run_device_cone)."""
+    can carry into that range any more (soda_hip_run_device_cone).  NOTE: the
+    last pass still writes up to `fused iterations x reach` rows on either
+    side of [lo, hi) -- computed with zeros where the launch ended, i.e. wrong
+    -- and leaves the rows beyond those untouched: outside [lo, hi) the output
+    arrays are unspecified, not "unchanged".
+    With `keep`, a halo exchange can run underneath (soda_hip_run_device_slab):
+    `ghosts` = (lo, hi) rows at either end of the INPUT arrays that an exchange
+    on another stream is writing, complete when the hipEvent_t `ghosts_ready`
+    fires; `sends` = (lo, hi) rows at either end of the kept range the
+    neighbours fetch next, complete when `sendable` (recorded by this call)
+    fires."""
     st = self.stencil
     iterate = st.iterate if iterate is None else iterate
     self._check_extent(extent)
@@ -704,6 +820,19 @@ class Program:
     ext = (ctypes.c_int32 * len(extent))(*extent)
     org = (ctypes.c_int32 * len(extent))(*(origin or [0] * len(extent)))
     gext = (ctypes.c_int32 * len(extent))(*(global_extent or extent))
+    if ghosts is not None or sends is not None or ghosts_ready or sendable:
+      keep = keep if keep is not None else (0, extent[-1])
+      reach_lo, reach_hi = st.reach_along(st.dim - 1)
+      run = SlabRun(int(keep[0]), int(keep[1]), reach_lo, reach_hi,
+                    *(int(v) for v in (ghosts or (0, 0))),
+                    *(int(v) for v in (sends or (0, 0))),
+                    ghosts_ready or None, sendable or None)
+      check(
+          self._lib.soda_hip_run_device_slab(
+              self._handle, outs, ins, ext, org, gext, iterate,
+              ctypes.byref(run), ctypes.c_void_p(stream)),
+          'running `%s`' % st.app_name)
+      return
     if keep is not None and tuple(keep) != (0, extent[-1]):
       reach_lo, reach_hi = st.reach_along(st.dim - 1)
       check(
@@ -717,6 +846,13 @@ class Program:
                                              gext, iterate,
                                              ctypes.c_void_p(stream)),
         'running `%s`' % st.app_name)
+
+  def last_split(self) -> int:
+    """Passes of the last run launched in two parts around a halo exchange."""
+    n = ctypes.c_int32()
+    check(self._lib.soda_hip_last_split(self._handle, ctypes.byref(n)),
+          'last_split')
+    return n.value
 
   def last_rows(self) -> int:
     """Cells along the last dimension the passes of the last run covered,
@@ -802,6 +938,196 @@ class Program:
         self._lib.soda_hip_run_host_box(self._handle, ins, outs, iterate, vlo,
                                         vhi), 'running `%s`' % st.app_name)
     return result
+
+
+def _host_tensor(arr, np_name: str, shape, dim: int, keep: list):
+  """HostTensor for a numpy array (shape = extent reversed), keeping the ctypes
+  arrays it points to alive in `keep`."""
+  import numpy as np
+  if arr.dtype != np.dtype(np_name):
+    raise util.InputError('expected dtype %s, got %s' % (np_name, arr.dtype))
+  if tuple(arr.shape) != tuple(shape):
+    raise util.InputError('all tensors must share one shape')
+  item = arr.dtype.itemsize
+  strides = [b // item for b in arr.strides[::-1]]
+  if any(v * item != b for v, b in zip(strides, arr.strides[::-1])):
+    raise util.InputError('strides must be whole elements')
+  ext = (ctypes.c_int32 * dim)(*shape[::-1])
+  strd = (ctypes.c_int32 * dim)(*strides)
+  mn = (ctypes.c_int32 * dim)(*([0] * dim))
+  keep.extend((ext, strd, mn, arr))
+  return HostTensor(arr.ctypes.data, ext, strd, mn)
+
+
+class Group:
+  """A SODA program on N GPUs driven by one host thread: the grid cut into
+  slabs along the streamed dimension, halo exchange by peer copies hidden under
+  the compute (soda_hip_group_*, include/soda_hip.h).  `devices` may name one
+  GPU several times ("virtual devices"): the whole N-slab schedule then runs on
+  that GPU -- how a one-GPU box tests it."""
+
+  def __init__(self, stencil: core.Stencil, extent: Sequence[int],
+               devices: Sequence[int],
+               opts: Optional[lower.LowerOptions] = None,
+               iterate: Optional[int] = None, exchange_every: int = 0,
+               overlap: bool = True, calibrate: bool = False):
+    self.stencil = stencil
+    self.extent = tuple(int(e) for e in extent)
+    self.devices = tuple(int(d) for d in devices)
+    if len(self.extent) != stencil.dim:
+      raise util.InputError('extent must have %d entries' % stencil.dim)
+    if not 1 <= len(self.devices) <= MAX_SLABS:
+      raise util.InputError('1 to %d slabs' % MAX_SLABS)
+    iterate = stencil.iterate if iterate is None else iterate
+    n = len(self.devices)
+    reach_lo, reach_hi = stencil.reach_along(stencil.dim - 1)
+    desc = GroupDesc()
+    desc.num_slabs = n
+    for i, d in enumerate(self.devices):
+      desc.device[i] = d
+    for i, e in enumerate(self.extent):
+      desc.extent[i] = e
+    desc.reach_lo, desc.reach_hi = reach_lo, reach_hi
+    desc.iterate = iterate
+    desc.exchange_every = exchange_every
+    desc.flags = (0 if overlap else GROUP_NO_OVERLAP) | (
+        GROUP_CALIBRATE if calibrate else 0)
+    self._lib = library()
+    # The kernels are shaped for the extent of a slab (row-covering blocks,
+    # how much warm-up to peel); a slab's extent depends on the exchange
+    # interval, which the library picks from the plan's pass times: lower once
+    # for the own rows, ask, lower again for the rows really held.
+    own = self.extent[-1] // n
+    every = ctypes.c_int32(exchange_every)
+    local = self.extent[:-1] + (max(1, own),)
+    for _ in range(2):
+      self.opts = resolve_options(stencil, opts, local)
+      self.module = lower.lower(stencil, self.opts)
+      self.code = compile_source(self.module.source,
+                                 '%s.hip' % stencil.app_name)
+      self.resources = kernel_resources(self.code)
+      self.plan = make_plan(self.module, self.resources)
+      check(self._lib.soda_hip_group_plan(ctypes.byref(self.plan),
+                                          ctypes.byref(desc),
+                                          ctypes.byref(every)),
+            'slabs of `%s`' % stencil.app_name)
+      ghosts = (reach_lo + reach_hi if n > 2 else max(reach_lo, reach_hi)
+                if n > 1 else 0) * every.value
+      grown = self.extent[:-1] + (own + ghosts,)
+      if grown == local:
+        break
+      local = grown
+    desc.exchange_every = every.value
+    self.exchange_every = every.value
+    self._handle = ctypes.c_void_p()
+    check(
+        self._lib.soda_hip_group_create(self.code, len(self.code),
+                                        ctypes.byref(self.plan),
+                                        ctypes.byref(desc),
+                                        ctypes.byref(self._handle)),
+        'loading `%s` on GPUs %s' % (stencil.app_name, list(self.devices)))
+    # (with calibrate=True the clock may have picked another interval)
+    self.exchange_every = int(self.stats()['exchange_every'])
+
+  def close(self) -> None:
+    if getattr(self, '_handle', None):
+      self._lib.soda_hip_group_destroy(self._handle)
+      self._handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  def slab(self, i: int) -> SlabInfo:
+    info = SlabInfo()
+    check(self._lib.soda_hip_group_slab(self._handle, i, ctypes.byref(info)),
+          'slab %d' % i)
+    return info
+
+  def load(self, inputs: Dict[str, 'numpy.ndarray']) -> None:
+    """Scatters the global input arrays (and params) over the slabs."""
+    import numpy as np
+    st = self.stencil
+    shape = self.extent[::-1]
+    keep: list = []
+    tensors = [_host_tensor(np.asarray(inputs[n]), t.np_name, shape, st.dim,
+                            keep)
+               for n, t in zip(st.input_names, st.input_types)]
+    for pstmt in st.param_stmts:
+      arr = np.ascontiguousarray(inputs[pstmt.name]).reshape(-1)
+      if arr.dtype != np.dtype(pstmt.haoda_type.np_name) or \
+          arr.size != st.param_elems(pstmt):
+        raise util.InputError('param %s must be %d x %s' % (
+            pstmt.name, st.param_elems(pstmt), pstmt.haoda_type.np_name))
+      keep.append(arr)
+      tensors.append(HostTensor(arr.ctypes.data, None, None, None))
+    arr_t = (HostTensor * len(tensors))(*tensors)
+    check(self._lib.soda_hip_group_load(self._handle, arr_t), 'group load')
+
+  def loaded(self) -> None:
+    """The caller filled the slabs' input arrays on the devices itself."""
+    check(self._lib.soda_hip_group_loaded(self._handle), 'group loaded')
+
+  def run(self, iterate: Optional[int] = None) -> None:
+    """Enqueues `iterate` iterations on every slab; asynchronous."""
+    iterate = self.stencil.iterate if iterate is None else iterate
+    check(self._lib.soda_hip_group_run(self._handle, iterate),
+          'running `%s` on %d slabs' % (self.stencil.app_name,
+                                        len(self.devices)))
+
+  def synchronize(self) -> None:
+    check(self._lib.soda_hip_group_synchronize(self._handle),
+          'group synchronize')
+
+  def store(self, iterate: Optional[int] = None,
+            outputs: Optional[Dict[str, 'numpy.ndarray']] = None
+            ) -> Dict[str, 'numpy.ndarray']:
+    """Gathers the results; only the valid box of `iterate` iterations of each
+    output is written (the rest keeps what the caller's array held, zeros for
+    arrays allocated here)."""
+    import numpy as np
+    st = self.stencil
+    iterate = st.iterate if iterate is None else iterate
+    shape = self.extent[::-1]
+    keep: list = []
+    result = {}
+    for n, t in zip(st.output_names, st.output_types):
+      result[n] = outputs[n] if outputs is not None and n in outputs else \
+          np.zeros(shape, dtype=np.dtype(t.np_name))
+    outs = (HostTensor * len(st.output_names))(*[
+        _host_tensor(result[n], t.np_name, shape, st.dim, keep)
+        for n, t in zip(st.output_names, st.output_types)])
+    lo, hi = [], []
+    for n in st.output_names:
+      l, h = st.valid_box(self.extent, n, iterate)
+      lo.extend(l)
+      hi.extend(max(a, b) for a, b in zip(h, l))
+    vlo = (ctypes.c_int32 * len(lo))(*lo)
+    vhi = (ctypes.c_int32 * len(hi))(*hi)
+    check(self._lib.soda_hip_group_store(self._handle, outs, vlo, vhi),
+          'group store')
+    return result
+
+  def run_host(self, inputs: Dict[str, 'numpy.ndarray'],
+               iterate: Optional[int] = None) -> Dict[str, 'numpy.ndarray']:
+    """numpy in, numpy out: load, run, store (soda::app::<app>() on N GPUs)."""
+    self.load(inputs)
+    self.run(iterate)
+    return self.store(iterate)
+
+  def stats(self) -> Dict[str, float]:
+    st = GroupStats()
+    check(self._lib.soda_hip_group_last_stats(self._handle, ctypes.byref(st)),
+          'group stats')
+    return {name: getattr(st, name) for name, _ in GroupStats._fields_}
 
 
 class Event:

@@ -35,8 +35,9 @@ def test_struct_mirrors_match(built):
   from soda_amd import runtime
   lib = runtime.library()   # also runs the built-in layout check
   assert lib.soda_hip_abi_version() == runtime.ABI_VERSION
-  # buf, stride, extent, ntile, tile, origin, gextent
-  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 5 * 4 * 4
+  # buf, stride, extent, ntile, tile, origin, gextent; skip_from, skip_count,
+  # reserved[2]
+  assert lib.soda_hip_sizeof(0) == 16 * 8 + 4 * 8 + 5 * 4 * 4 + 4 * 4
   assert lib.soda_hip_sizeof(3) == ctypes.sizeof(runtime.Plan)
   assert lib.soda_hip_sizeof(99) == 0
   assert lib.soda_hip_status_string(5) == b'no usable GPU'
@@ -48,6 +49,8 @@ def test_kargs_struct_in_device_runtime_matches_header():
   assert 'void* buf[16];' in rt and 'int64_t stride[4];' in rt
   assert 'int32_t extent[4];' in rt and 'int32_t ntile[4];' in rt
   assert 'int32_t tile[4];' in rt
+  assert rt.index('gextent[4]') < rt.index('skip_from;') < rt.index(
+      'skip_count;') < rt.index('reserved[2];')
 
 
 ALL = sorted(f for f in os.listdir(SODA_DIR) if f.endswith('.soda')) + [
