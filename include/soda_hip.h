@@ -278,10 +278,11 @@ int soda_hip_run_device_cone(soda_hip_program_t* program,
  *                        recorded exactly once per call; NULL: none) fires
  *                        behind them, the rest of the pass follows -- the
  *                        next exchange may start while it computes.
- * A split pass runs its two parts on two streams (the boundary chunks on a
- * stream the program owns, ordered against `stream` by events) so they share
- * the GPU.  Passes that are not one marching kernel along the last dimension
- * run whole: wait, compute, signal.  The reference has no counterpart (one
+ * A split pass is two launches on `stream`, the part that does not depend on
+ * the exchange first (environment SODA_HIP_SPLIT=side: the boundary chunks on
+ * a stream the program owns, ordered against `stream` by events, so the parts
+ * share the GPU -- measured slower).  Passes that are not one
+ * marching kernel along the last dimension run whole: wait, compute, signal.  The reference has no counterpart (one
  * device, frt/host.py:319-322); SURVEY.md 8(e): "compute boundary planes
  * first, send, compute interior". */
 typedef struct soda_hip_slab_run {
@@ -402,6 +403,13 @@ int soda_hip_last_split(soda_hip_program_t* program, int32_t* passes);
 #define SODA_HIP_GROUP_NO_OVERLAP 1    /* exchange, then compute: for A/B runs */
 #define SODA_HIP_GROUP_CALIBRATE 2     /* time every pass on every slab extent
                                           once (soda_hip_program_calibrate) */
+
+#define SODA_HIP_GROUP_THREADS 4       /* one enqueueing thread per slab inside
+                                          the library: the caller still sees one
+                                          blocking sequence, but a step of
+                                          9 launches x 8 GPUs no longer costs
+                                          0.3 ms of ONE thread's time, as long
+                                          as the GPUs take to run it */
 
 typedef struct soda_hip_group_desc {
   int32_t num_slabs;
@@ -568,6 +576,14 @@ int soda_hip_event_record(soda_hip_event_t* event, void* stream);
 int soda_hip_event_elapsed_ms(soda_hip_event_t* start, soda_hip_event_t* stop,
                               float* ms);   /* synchronises on `stop` */
 int soda_hip_event_destroy(soda_hip_event_t* event);
+/* For callers that run their own halo exchange beside
+ * soda_hip_run_device_slab: the hipEvent_t inside an event (what
+ * soda_hip_slab_run_t takes), a HIP stream of their own, and ordering a
+ * stream behind an event. */
+int soda_hip_event_handle(soda_hip_event_t* event, void** hip_event);
+int soda_hip_hipstream_create(int32_t device, void** stream);
+int soda_hip_hipstream_destroy(void* stream);
+int soda_hip_hipstream_wait_event(void* stream, soda_hip_event_t* event);
 
 #ifdef __cplusplus
 }

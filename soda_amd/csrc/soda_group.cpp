@@ -25,9 +25,14 @@
 // neighbour's B(last) -> S -> my next copy -> my B(first) -> my last pass.
 #include "soda_internal.h"
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 
 using namespace soda_detail;
 
@@ -41,11 +46,21 @@ struct Slab {
   int32_t extent[SODA_HIP_MAX_DIM];
   int32_t origin[SODA_HIP_MAX_DIM];
   std::vector<DeviceBuffer> a, b, params;
-  std::vector<void*> cur, nxt;     // inputs of the next interval / its outputs
-  std::vector<void*> result;       // outputs of the last run
+  // the two array sets the state ping-pongs between: a program that iterates
+  // reads side[j & 1] and writes the other in interval j (counted since the
+  // group was made, the same on every slab); any other reads a, writes b
+  std::vector<void*> side[2];
   hipStream_t main = nullptr, comm = nullptr;
-  hipEvent_t ghosts_ready[2] = {nullptr, nullptr};
+  hipEvent_t ghosts_ready[2] = {nullptr, nullptr};   // by interval parity
   hipEvent_t sendable[2] = {nullptr, nullptr};
+  // intervals whose launches (and `sendable` record) are enqueued: what a
+  // neighbour's enqueueing thread waits for before it orders a copy behind them
+  std::atomic<int64_t> enqueued{0};
+  // of the last run (summed over the slabs for soda_hip_group_last_stats)
+  int32_t copies = 0, launches = 0, split_passes = 0;
+  int64_t copy_bytes = 0;
+  int rc = 0;
+  std::string error;
 };
 
 // Transfer model behind the choice of the exchange interval.  A peer copy
@@ -65,11 +80,27 @@ struct soda_hip_group {
   int32_t every = 1;           // iterations between exchanges
   bool iterable = false;       // outputs feed the inputs of the next run
   bool loaded = false;
-  bool fresh = false;          // ghost rows of `cur` hold neighbour data
-  int turn = 0;                // event set the next interval records
+  bool fresh = false;          // ghost rows of the state hold neighbour data
+  int64_t interval = 0;        // intervals run since the group was made
   int64_t row_cells = 1;
-  std::vector<Slab> slabs;
+  std::vector<std::unique_ptr<Slab>> slabs;
   soda_hip_group_stats_t stats;
+  // SODA_HIP_GROUP_THREADS: one enqueueing thread per slab
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  int64_t job = 0;             // number of the run the workers should enqueue
+  int32_t job_iterate = 0;
+  int finished = 0;
+  bool stop = false;
+  std::atomic<bool> failed{false};
+
+  const std::vector<void*>& inputs_of(const Slab& s, int64_t j) const {
+    return s.side[iterable ? (int)(j & 1) : 0];
+  }
+  const std::vector<void*>& outputs_of(const Slab& s, int64_t j) const {
+    return s.side[iterable ? (int)((j & 1) ^ 1) : 1];
+  }
 };
 
 namespace {
@@ -282,10 +313,11 @@ int copy_rows(const Slab& to, void* dst, const Slab& from, const void* src,
   return SODA_HIP_OK;
 }
 
-// refreshes slab s's ghost rows of `cur` from the neighbours' own rows
-int enqueue_exchange(soda_hip_group* g, int s) {
-  Slab& me = g->slabs[s];
-  const int prev = g->turn ^ 1;
+// refreshes slab s's ghost rows of the state interval j starts from, from the
+// neighbours' own rows
+int enqueue_exchange(soda_hip_group* g, int s, int64_t j) {
+  Slab& me = *g->slabs[s];
+  const int prev = (int)((j - 1) & 1);
   const int n = (int)g->slabs.size();
   HIP_TRY(hipSetDevice(me.device));
   HIP_TRY(hipStreamWaitEvent(me.comm, me.sendable[prev], 0));
@@ -293,27 +325,29 @@ int enqueue_exchange(soda_hip_group* g, int s) {
     const int peer = side == 0 ? s - 1 : s + 1;
     const int32_t ghost = side == 0 ? me.ghost_lo : me.ghost_hi;
     if (peer < 0 || peer >= n || ghost == 0) continue;
-    Slab& nb = g->slabs[peer];
+    Slab& nb = *g->slabs[peer];
     HIP_TRY(hipStreamWaitEvent(me.comm, nb.sendable[prev], 0));
     // global rows fetched, then local rows on either side
     const int32_t g0 = side == 0 ? me.begin : me.own_end;
     for (int t = 0; t < g->plan.num_inputs; ++t) {
       const int64_t row_bytes = g->row_cells * g->plan.elem_size[t];
-      char* dst = static_cast<char*>(me.cur[t]) + (int64_t)(g0 - me.begin) * row_bytes;
-      const char* src = static_cast<const char*>(nb.cur[t]) +
+      char* dst = static_cast<char*>(g->inputs_of(me, j)[t]) +
+                  (int64_t)(g0 - me.begin) * row_bytes;
+      const char* src = static_cast<const char*>(g->inputs_of(nb, j)[t]) +
                         (int64_t)(g0 - nb.begin) * row_bytes;
       if (int rc = copy_rows(me, dst, nb, src, (size_t)ghost * row_bytes))
         return rc;
-      ++g->stats.copies;
-      g->stats.copy_bytes += (int64_t)ghost * row_bytes;
+      ++me.copies;
+      me.copy_bytes += (int64_t)ghost * row_bytes;
     }
   }
-  HIP_TRY(hipEventRecord(me.ghosts_ready[g->turn], me.comm));
+  HIP_TRY(hipEventRecord(me.ghosts_ready[j & 1], me.comm));
   return SODA_HIP_OK;
 }
 
-int enqueue_interval(soda_hip_group* g, int s, int32_t iters, bool exchanged) {
-  Slab& me = g->slabs[s];
+int enqueue_interval(soda_hip_group* g, int s, int64_t j, int32_t iters,
+                     bool exchanged) {
+  Slab& me = *g->slabs[s];
   const int n = (int)g->slabs.size();
   const bool overlap = !(g->desc.flags & SODA_HIP_GROUP_NO_OVERLAP);
   SlabRun run;
@@ -322,32 +356,83 @@ int enqueue_interval(soda_hip_group* g, int s, int32_t iters, bool exchanged) {
   run.ghost_lo = exchanged ? me.ghost_lo : 0;
   run.ghost_hi = exchanged ? me.ghost_hi : 0;
   // what the neighbours fetch: their ghost rows on the side that faces me
-  run.send_lo = s > 0 ? g->slabs[s - 1].ghost_hi : 0;
-  run.send_hi = s < n - 1 ? g->slabs[s + 1].ghost_lo : 0;
-  run.ghosts_ready = exchanged ? me.ghosts_ready[g->turn] : nullptr;
-  run.sendable = n > 1 ? me.sendable[g->turn] : nullptr;
+  run.send_lo = s > 0 ? g->slabs[s - 1]->ghost_hi : 0;
+  run.send_hi = s < n - 1 ? g->slabs[s + 1]->ghost_lo : 0;
+  run.ghosts_ready = exchanged ? me.ghosts_ready[j & 1] : nullptr;
+  run.sendable = n > 1 ? me.sendable[j & 1] : nullptr;
   HIP_TRY(hipSetDevice(me.device));
+  hipEvent_t after = nullptr;
   if (!overlap) {     // exchange, compute, signal -- nothing runs underneath
     if (run.ghosts_ready) HIP_TRY(hipStreamWaitEvent(me.main, run.ghosts_ready, 0));
-    hipEvent_t after = run.sendable;
+    after = run.sendable;
     run.ghosts_ready = run.sendable = nullptr;
     run.ghost_lo = run.ghost_hi = run.send_lo = run.send_hi = 0;
-    std::vector<const void*> ins(me.cur.begin(), me.cur.end());
-    for (auto& prm : me.params) ins.push_back(prm.ptr);
-    if (int rc = run_core(me.prog, me.nxt.data(), ins.data(), me.extent,
-                          me.origin, g->desc.extent, iters, me.main, -1, &run))
-      return rc;
-    if (after) HIP_TRY(hipEventRecord(after, me.main));
-  } else {
-    std::vector<const void*> ins(me.cur.begin(), me.cur.end());
-    for (auto& prm : me.params) ins.push_back(prm.ptr);
-    if (int rc = run_core(me.prog, me.nxt.data(), ins.data(), me.extent,
-                          me.origin, g->desc.extent, iters, me.main, -1, &run))
-      return rc;
   }
-  g->stats.launches += me.prog->last_launches;
-  g->stats.split_passes += me.prog->last_split;
+  const std::vector<void*>& cur = g->inputs_of(me, j);
+  std::vector<const void*> ins(cur.begin(), cur.end());
+  for (auto& prm : me.params) ins.push_back(prm.ptr);
+  std::vector<void*> outs = g->outputs_of(me, j);
+  if (int rc = run_core(me.prog, outs.data(), ins.data(), me.extent, me.origin,
+                        g->desc.extent, iters, me.main, -1, &run))
+    return rc;
+  if (after) HIP_TRY(hipEventRecord(after, me.main));
+  me.launches += me.prog->last_launches;
+  me.split_passes += me.prog->last_split;
   return SODA_HIP_OK;
+}
+
+// Everything slab s has to enqueue for a run of `iterate` iterations that
+// starts at interval j0.  Threaded: before a copy is ordered behind a
+// neighbour's `sendable`, that neighbour's thread must have RECORDED it.
+int enqueue_slab_run(soda_hip_group* g, int s, int64_t j0, int32_t iterate,
+                     bool fresh) {
+  const int n = (int)g->slabs.size();
+  Slab& me = *g->slabs[s];
+  int32_t done = 0;
+  for (int64_t j = j0; done < iterate; ++j) {
+    const int32_t k = iterate - done < g->every ? iterate - done : g->every;
+    const bool exchange = !fresh && n > 1;
+    if (exchange) {
+      for (int peer = s - 1; peer <= s + 1; peer += 2)
+        if (peer >= 0 && peer < n)
+          while (g->slabs[peer]->enqueued.load(std::memory_order_acquire) < j) {
+            if (g->failed.load()) return fail(SODA_HIP_ERR_RUNTIME,
+                                              "another slab's thread failed");
+            std::this_thread::yield();
+          }
+      if (int rc = enqueue_exchange(g, s, j)) return rc;
+    }
+    if (int rc = enqueue_interval(g, s, j, k, exchange)) return rc;
+    me.enqueued.store(j + 1, std::memory_order_release);
+    fresh = !g->iterable;
+    done += k;
+  }
+  return SODA_HIP_OK;
+}
+
+void worker_main(soda_hip_group* g, int s) {
+  int64_t seen = 0;
+  for (;;) {
+    int32_t iterate;
+    {
+      std::unique_lock<std::mutex> lock(g->mu);
+      g->cv_job.wait(lock, [&] { return g->stop || g->job > seen; });
+      if (g->stop) return;
+      seen = g->job;
+      iterate = g->job_iterate;
+    }
+    Slab& me = *g->slabs[s];
+    me.rc = enqueue_slab_run(g, s, g->interval, iterate, g->fresh);
+    if (me.rc) {
+      me.error = last_error_text();
+      g->failed.store(true);
+    }
+    {
+      std::lock_guard<std::mutex> lock(g->mu);
+      ++g->finished;
+    }
+    g->cv_done.notify_one();
+  }
 }
 
 void destroy_slab(Slab& s) {
@@ -365,7 +450,7 @@ void destroy_slab(Slab& s) {
 }
 
 int create_slab(soda_hip_group* g, int s, const void* code, size_t code_size) {
-  Slab& me = g->slabs[s];
+  Slab& me = *g->slabs[s];
   const soda_hip_plan_t& plan = g->plan;
   if (int rc = soda_hip_program_create(code, code_size, &plan, me.device, &me.prog))
     return rc;
@@ -382,14 +467,13 @@ int create_slab(soda_hip_group* g, int s, const void* code, size_t code_size) {
   me.params.resize(plan.num_params);
   for (int t = 0; t < plan.num_inputs; ++t) {
     if (int rc = ensure(me.a[t], (size_t)cells * plan.elem_size[t])) return rc;
-    me.cur.push_back(me.a[t].ptr);
+    me.side[0].push_back(me.a[t].ptr);
   }
   for (int o = 0; o < plan.num_outputs; ++o) {
     if (int rc = ensure(me.b[o], (size_t)cells * plan.elem_size[plan.num_inputs + o]))
       return rc;
-    me.nxt.push_back(me.b[o].ptr);
+    me.side[1].push_back(me.b[o].ptr);
   }
-  me.result = me.nxt;
   const int prm0 = plan.num_inputs + plan.num_outputs + plan.num_locals;
   for (int k = 0; k < plan.num_params; ++k)
     if (int rc = ensure(me.params[k],
@@ -461,11 +545,11 @@ int soda_hip_group_create(const void* code, size_t code_size,
   memset(&g->stats, 0, sizeof g->stats);
   g->stats.exchange_every = every;
   for (int i = 0; i < plan->dim - 1; ++i) g->row_cells *= desc->extent[i];
-  g->slabs.resize(desc->num_slabs);
   int rc = SODA_HIP_OK;
   for (int s = 0; s < desc->num_slabs && rc == SODA_HIP_OK; ++s) {
-    g->slabs[s].device = desc->device[s];
-    slab_rows(*desc, plan->dim, every, s, &g->slabs[s]);
+    g->slabs.emplace_back(new Slab);
+    g->slabs[s]->device = desc->device[s];
+    slab_rows(*desc, plan->dim, every, s, g->slabs[s].get());
     rc = create_slab(g, s, code, code_size);
   }
   // neighbours on different GPUs copy peer to peer over xGMI
@@ -484,7 +568,7 @@ int soda_hip_group_create(const void* code, size_t code_size,
   }
   if (rc == SODA_HIP_OK && (desc->flags & SODA_HIP_GROUP_CALIBRATE))
     for (auto& sl : g->slabs) {
-      rc = soda_hip_program_calibrate(sl.prog, sl.extent, 4, sl.main);
+      rc = soda_hip_program_calibrate(sl->prog, sl->extent, 4, sl->main);
       if (rc) break;
     }
   if (rc) {
@@ -492,20 +576,31 @@ int soda_hip_group_create(const void* code, size_t code_size,
     soda_hip_group_destroy(g);
     return fail(rc, why);
   }
+  if ((desc->flags & SODA_HIP_GROUP_THREADS) && desc->num_slabs > 1)
+    for (int s = 0; s < desc->num_slabs; ++s)
+      g->workers.emplace_back(worker_main, g, s);
   *group = g;
   return SODA_HIP_OK;
 }
 
 int soda_hip_group_destroy(soda_hip_group_t* g) {
   if (!g) return SODA_HIP_OK;
+  if (!g->workers.empty()) {
+    {
+      std::lock_guard<std::mutex> lock(g->mu);
+      g->stop = true;
+    }
+    g->cv_job.notify_all();
+    for (auto& w : g->workers) w.join();
+  }
   for (auto& s : g->slabs) {
-    if (s.main) {
-      (void)hipSetDevice(s.device);
-      (void)hipStreamSynchronize(s.main);
-      (void)hipStreamSynchronize(s.comm);
+    if (s->main) {
+      (void)hipSetDevice(s->device);
+      (void)hipStreamSynchronize(s->main);
+      (void)hipStreamSynchronize(s->comm);
     }
   }
-  for (auto& s : g->slabs) destroy_slab(s);
+  for (auto& s : g->slabs) destroy_slab(*s);
   delete g;
   return SODA_HIP_OK;
 }
@@ -515,7 +610,7 @@ int soda_hip_group_slab(soda_hip_group_t* g, int32_t slab,
   if (!g || !info) return fail(SODA_HIP_ERR_INVALID, "group_slab: NULL argument");
   if (slab < 0 || slab >= (int32_t)g->slabs.size())
     return fail(SODA_HIP_ERR_INVALID, "group_slab: no such slab");
-  const Slab& s = g->slabs[slab];
+  const Slab& s = *g->slabs[slab];
   memset(info, 0, sizeof *info);
   info->device = s.device;
   info->begin = s.begin;
@@ -525,8 +620,12 @@ int soda_hip_group_slab(soda_hip_group_t* g, int32_t slab,
   info->ghost_lo = s.ghost_lo;
   info->ghost_hi = s.ghost_hi;
   for (int i = 0; i < SODA_HIP_MAX_DIM; ++i) info->extent[i] = s.extent[i];
-  for (size_t t = 0; t < s.cur.size(); ++t) info->inputs[t] = s.cur[t];
-  for (size_t o = 0; o < s.result.size(); ++o) info->outputs[o] = s.result[o];
+  // the state the next interval reads; the results of the last one (for a
+  // program that iterates the same arrays)
+  const std::vector<void*>& in = g->inputs_of(s, g->interval);
+  const std::vector<void*>& out = g->iterable ? in : s.side[1];
+  for (size_t t = 0; t < in.size(); ++t) info->inputs[t] = in[t];
+  for (size_t o = 0; o < out.size(); ++o) info->outputs[o] = out[o];
   return SODA_HIP_OK;
 }
 
@@ -557,9 +656,10 @@ int soda_hip_group_load(soda_hip_group_t* g,
     }
     const int64_t row_bytes = g->row_cells * elem;
     for (auto& s : g->slabs) {
-      HIP_TRY(hipSetDevice(s.device));
-      HIP_TRY(hipMemcpy(s.cur[t], host + (int64_t)s.begin * row_bytes,
-                        (size_t)(s.end - s.begin) * row_bytes,
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipMemcpy(g->inputs_of(*s, g->interval)[t],
+                        host + (int64_t)s->begin * row_bytes,
+                        (size_t)(s->end - s->begin) * row_bytes,
                         hipMemcpyHostToDevice));
     }
   }
@@ -569,8 +669,8 @@ int soda_hip_group_load(soda_hip_group_t* g,
     if (!host) return fail(SODA_HIP_ERR_INVALID, "group_load: NULL param");
     const size_t bytes = (size_t)plan.param_elems[k] * plan.elem_size[prm0 + k];
     for (auto& s : g->slabs) {
-      HIP_TRY(hipSetDevice(s.device));
-      HIP_TRY(hipMemcpy(s.params[k].ptr, host, bytes, hipMemcpyHostToDevice));
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipMemcpy(s->params[k].ptr, host, bytes, hipMemcpyHostToDevice));
     }
   }
   g->loaded = true;
@@ -598,41 +698,81 @@ int soda_hip_group_run(soda_hip_group_t* g, int32_t iterate) {
                 "iterate > 1 times");
   const auto t0 = std::chrono::steady_clock::now();
   const int n = (int)g->slabs.size();
+  const int32_t intervals = (iterate + g->every - 1) / g->every;
+  for (auto& s : g->slabs) {
+    s->copies = s->launches = s->split_passes = 0;
+    s->copy_bytes = 0;
+    s->rc = 0;
+  }
+  int rc = SODA_HIP_OK;
+  std::string why;
+  if (!g->workers.empty()) {
+    g->failed.store(false);
+    {
+      std::lock_guard<std::mutex> lock(g->mu);
+      g->job_iterate = iterate;
+      g->finished = 0;
+      ++g->job;
+    }
+    g->cv_job.notify_all();
+    {
+      std::unique_lock<std::mutex> lock(g->mu);
+      g->cv_done.wait(lock, [&] { return g->finished == n; });
+    }
+    for (auto& s : g->slabs)
+      if (s->rc && !rc) {
+        rc = s->rc;
+        why = s->error;
+      }
+  } else {
+    // one thread: interval by interval, so that every `sendable` is recorded
+    // before a neighbour's copy is ordered behind it
+    int32_t done = 0;
+    bool fresh = g->fresh;
+    for (int64_t j = g->interval; done < iterate && !rc; ++j) {
+      const int32_t k = iterate - done < g->every ? iterate - done : g->every;
+      const bool exchange = !fresh && n > 1;
+      for (int s = 0; exchange && s < n && !rc; ++s) rc = enqueue_exchange(g, s, j);
+      for (int s = 0; s < n && !rc; ++s) {
+        rc = enqueue_interval(g, s, j, k, exchange);
+        g->slabs[s]->enqueued.store(j + 1, std::memory_order_release);
+      }
+      fresh = !g->iterable;
+      done += k;
+    }
+    if (rc) why = last_error_text();
+  }
   soda_hip_group_stats_t& st = g->stats;
   memset(&st, 0, sizeof st);
   st.exchange_every = g->every;
-  int32_t done = 0;
-  while (done < iterate) {
-    const int32_t k = iterate - done < g->every ? iterate - done : g->every;
-    const bool exchange = !g->fresh && n > 1;
-    if (exchange) {
-      for (int s = 0; s < n; ++s)
-        if (int rc = enqueue_exchange(g, s)) return rc;
-      ++st.exchanges;
-    }
-    for (int s = 0; s < n; ++s)
-      if (int rc = enqueue_interval(g, s, k, exchange)) return rc;
-    for (auto& s : g->slabs) {
-      s.result = s.nxt;
-      if (g->iterable) std::swap(s.cur, s.nxt);
-    }
-    g->fresh = !g->iterable;      // a result's ghost rows are stale
-    g->turn ^= 1;
-    ++st.intervals;
-    done += k;
+  st.intervals = intervals;
+  st.exchanges = n > 1 ? intervals - (g->fresh ? 1 : 0) : 0;
+  for (auto& s : g->slabs) {
+    st.copies += s->copies;
+    st.copy_bytes += s->copy_bytes;
+    st.launches += s->launches;
+    st.split_passes += s->split_passes;
   }
+  // (the arrays a program that iterates reads next follow from the count)
+  g->interval += intervals;
+  for (auto& s : g->slabs) s->enqueued.store(g->interval);
+  g->fresh = !g->iterable;      // a result's ghost rows are stale
   st.enqueue_ms = std::chrono::duration<float, std::milli>(
                       std::chrono::steady_clock::now() - t0).count();
+  if (rc) {
+    g->loaded = false;          // the state is not what any caller expects
+    return fail(rc, why);
+  }
   return SODA_HIP_OK;
 }
 
 int soda_hip_group_synchronize(soda_hip_group_t* g) {
   if (!g) return fail(SODA_HIP_ERR_INVALID, "group_synchronize: NULL group");
   for (auto& s : g->slabs) {
-    HIP_TRY(hipSetDevice(s.device));
-    HIP_TRY(hipStreamSynchronize(s.main));
-    HIP_TRY(hipStreamSynchronize(s.comm));
-    if (s.prog->side) HIP_TRY(hipStreamSynchronize(s.prog->side));
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->main));
+    HIP_TRY(hipStreamSynchronize(s->comm));
+    if (s->prog->side) HIP_TRY(hipStreamSynchronize(s->prog->side));
   }
   return SODA_HIP_OK;
 }
@@ -670,11 +810,13 @@ int soda_hip_group_store(soda_hip_group_t* g,
       dense = staging.data();
     }
     for (auto& s : g->slabs) {
-      HIP_TRY(hipSetDevice(s.device));
-      HIP_TRY(hipMemcpy(dense + (int64_t)s.own_begin * row_bytes,
-                        static_cast<const char*>(s.result[o]) +
-                            (int64_t)(s.own_begin - s.begin) * row_bytes,
-                        (size_t)(s.own_end - s.own_begin) * row_bytes,
+      const void* result = g->iterable ? g->inputs_of(*s, g->interval)[o]
+                                       : s->side[1][o];
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipMemcpy(dense + (int64_t)s->own_begin * row_bytes,
+                        static_cast<const char*>(result) +
+                            (int64_t)(s->own_begin - s->begin) * row_bytes,
+                        (size_t)(s->own_end - s->own_begin) * row_bytes,
                         hipMemcpyDeviceToHost));
     }
     // only the valid box reaches the caller's array (frt/host.py:357-375)

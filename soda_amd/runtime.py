@@ -42,6 +42,7 @@ MAX_SLABS = 64
 NAME_LEN = 96
 GROUP_NO_OVERLAP = 1
 GROUP_CALIBRATE = 2
+GROUP_THREADS = 4
 ABI_VERSION = 6
 
 
@@ -257,6 +258,10 @@ API = {
         _vp, _vp, ctypes.POINTER(ctypes.c_float)
     ]),
     'soda_hip_event_destroy': (ctypes.c_int, [_vp]),
+    'soda_hip_event_handle': (ctypes.c_int, [_vp, _pvp]),
+    'soda_hip_hipstream_create': (ctypes.c_int, [_i32, _pvp]),
+    'soda_hip_hipstream_destroy': (ctypes.c_int, [_vp]),
+    'soda_hip_hipstream_wait_event': (ctypes.c_int, [_vp, _vp]),
 }
 
 _lib = None
@@ -970,7 +975,10 @@ class Group:
                devices: Sequence[int],
                opts: Optional[lower.LowerOptions] = None,
                iterate: Optional[int] = None, exchange_every: int = 0,
-               overlap: bool = True, calibrate: bool = False):
+               overlap: bool = True, calibrate: bool = False,
+               threads: Optional[bool] = None):
+    """`threads`: one enqueueing thread per slab inside the library (default:
+    when the slabs sit on more than one GPU)."""
     self.stencil = stencil
     self.extent = tuple(int(e) for e in extent)
     self.devices = tuple(int(d) for d in devices)
@@ -990,8 +998,11 @@ class Group:
     desc.reach_lo, desc.reach_hi = reach_lo, reach_hi
     desc.iterate = iterate
     desc.exchange_every = exchange_every
+    if threads is None:
+      threads = len(set(self.devices)) > 1
     desc.flags = (0 if overlap else GROUP_NO_OVERLAP) | (
-        GROUP_CALIBRATE if calibrate else 0)
+        GROUP_CALIBRATE if calibrate else 0) | (
+            GROUP_THREADS if threads else 0)
     self._lib = library()
     # The kernels are shaped for the extent of a slab (row-covering blocks,
     # how much warm-up to peel); a slab's extent depends on the exchange
@@ -1143,6 +1154,13 @@ class Event:
     check(self._lib.soda_hip_event_record(self._h, ctypes.c_void_p(stream)),
           'event_record')
 
+  def handle(self) -> int:
+    """The hipEvent_t inside (what run_device's ghosts_ready / sendable take)."""
+    h = ctypes.c_void_p()
+    check(self._lib.soda_hip_event_handle(self._h, ctypes.byref(h)),
+          'event_handle')
+    return h.value
+
   def elapsed_ms(self, stop: 'Event') -> float:
     ms = ctypes.c_float()
     check(self._lib.soda_hip_event_elapsed_ms(self._h, stop._h,
@@ -1154,6 +1172,43 @@ class Event:
     try:
       if self._h:
         self._lib.soda_hip_event_destroy(self._h)
+    except Exception:
+      pass
+
+
+class Stream:
+  """A HIP stream of the caller's own (for a halo exchange that runs beside
+  Program.run_device)."""
+
+  def __init__(self, device: int = 0):
+    self._lib = library()
+    self._h = ctypes.c_void_p()
+    check(self._lib.soda_hip_hipstream_create(device, ctypes.byref(self._h)),
+          'hipstream_create')
+    self.device = device
+
+  @property
+  def handle(self) -> int:
+    return self._h.value
+
+  def wait_event(self, event: Event) -> None:
+    check(self._lib.soda_hip_hipstream_wait_event(self._h, event._h),
+          'hipstream_wait_event')
+
+  def copy(self, dst: int, src: int, nbytes: int,
+           src_device: Optional[int] = None) -> None:
+    check(self._lib.soda_hip_memcpy_d2d(
+        ctypes.c_void_p(dst), self.device, ctypes.c_void_p(src),
+        self.device if src_device is None else src_device, nbytes, self._h),
+          'memcpy_d2d')
+
+  def synchronize(self) -> None:
+    check(self._lib.soda_hip_stream_synchronize(self._h), 'stream_synchronize')
+
+  def __del__(self):
+    try:
+      if self._h:
+        self._lib.soda_hip_hipstream_destroy(self._h)
     except Exception:
       pass
 

@@ -280,6 +280,39 @@ def test_chained_group_runs_continue_from_the_result(built):
   _check(stencil, extent, got, want, 30)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,extent,iterate,fuse,slabs,every', [
+    ('jacobi2d.soda', (512, 960), 47, (4,), 8, 4),
+    ('heat3d.soda', (64, 48, 96), 9, (2,), 4, 2),
+    ('jacobi2d.soda', (512, 480), 5, (), 3, 1),
+])
+def test_one_enqueueing_thread_per_slab(built, name, extent, iterate, fuse,
+                                        slabs, every):
+  """SODA_HIP_GROUP_THREADS: the slabs' launches are enqueued by a thread each
+  (a neighbour's `sendable` must be recorded before a copy is ordered behind
+  it: the threads hand that over among themselves); same results, run after
+  run."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  inputs = _inputs(stencil, extent, 11)
+  want = _oracle(stencil, inputs, 2 * iterate)
+  with runtime.Group(stencil, extent, [0] * slabs,
+                     lower.LowerOptions(fuse=fuse), exchange_every=every,
+                     threads=True) as group:
+    group.load(inputs)
+    group.run()
+    first = group.stats()
+    group.run()
+    st = group.stats()
+    got = group.store(2 * iterate)
+  _check(stencil, extent, got, want, 2 * iterate)
+  rounds = -(-iterate // every)
+  assert (first['intervals'], first['exchanges']) == (rounds, rounds - 1)
+  assert (st['intervals'], st['exchanges']) == (rounds, rounds)
+  assert st['copies'] == rounds * 2 * (slabs - 1)
+
+
 C5 = ('jacobi2d.soda', (8192, 8192), 1000, (12, 4), 3)
 C4 = ('heat3d.soda', (512, 512, 512), 50, (2,), 2)
 
