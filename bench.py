@@ -16,7 +16,17 @@ Besides the contract's fields the JSON line carries
   cpu_baseline  the CPU oracle ("port" of the reference's loop nest, OpenMP on
                 all host cores) timed on a bounded sample -- rank 0, N = 1 only;
   single_iter   the same workload with one iteration per launch (no temporal
-                blocking), for the "LDS/register halo tile" config of BASELINE.
+                blocking), for the "LDS/register halo tile" config of BASELINE;
+  rehearsed_scaling  (N = 1) what an N-GPU job would score if every rank ran
+                its slab at the speed measured here for the middle rank's slab
+                (compute only, no exchange).
+
+N > 1 under torchrun: every step opens with a halo exchange; `--overlap auto`
+(default) times a few steps with the exchange hidden under the compute
+(soda_hip_run_device_slab) and a few without, all ranks agree on the faster
+way (MAX over ranks), and the timed steps use it.  `--group`: ONE process
+drives all N GPUs through soda_hip_group_* instead (peer copies, no RCCL);
+`--group --virtual` puts the N slabs on one GPU.
 """
 import argparse
 import json
@@ -63,6 +73,14 @@ def parse_args():
                   'an N-GPU run; only valid when no exchange is needed; the '
                   'JSON value is then what the N-GPU job would score if every '
                   'rank ran at this speed')
+  ap.add_argument('--overlap', choices=('auto', 'on', 'off'), default='auto',
+                  help='N > 1: hide the halo exchange under the compute')
+  ap.add_argument('--group', action='store_true',
+                  help='one process, N GPUs through soda_hip_group_* (peer '
+                  'copies over xGMI) instead of one rank per GPU over RCCL')
+  ap.add_argument('--virtual', action='store_true',
+                  help='with --group: all N slabs on GPU 0')
+  ap.add_argument('--no-rehearsal', action='store_true')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-single-iter', action='store_true')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
@@ -105,6 +123,17 @@ def cpu_baseline(stencil, extent, target_seconds):
   t0 = time.time()
   orc.run(a, iterate=iters)
   dt = time.time() - t0
+  # g++ -O2 single-thread AND OpenMP.  One thread takes ~0.2 s
+  # per iteration of this grid: a few iterations, stated
+  one = c_oracle.COracle(stencil, openmp=False)
+  one.run(a, iterate=1)
+  t0 = time.time()
+  one.run(a, iterate=1)
+  t1 = max(1e-4, time.time() - t0)
+  iters1 = int(max(2, min(200, 0.25 * target_seconds / t1)))
+  t0 = time.time()
+  one.run(a, iterate=iters1)
+  dt1 = time.time() - t0
   return {
       'value': cells * iters / dt, 'unit': 'cells*iters/s', 'cores': cores,
       'kind': 'port',
@@ -112,7 +141,145 @@ def cpu_baseline(stencil, extent, target_seconds):
                 '-fopenmp, %d threads' % (stencil.app_name,
                                           'x'.join(map(str, extent)), iters,
                                           dt, cores),
+      'single_thread': {
+          'value': cells * iters1 / dt1, 'unit': 'cells*iters/s', 'cores': 1,
+          'kind': 'port',
+          'sample': '%s %s, iterate=%d (%.1f s), gcc -O2 -ffp-contract=off, '
+                    '1 thread' % (stencil.app_name, 'x'.join(map(str, extent)),
+                                  iters1, dt1),
+      },
   }
+
+
+def rehearse(args, stencil, extent, fuses, options, stream, value_1gpu):
+  """Compute-only scaling, measured in this process: for N = 2, 4, 8 the slab
+  of the middle rank of an N-GPU run (its ghost rows included, cone-trimmed
+  passes, the library's schedule for that extent), `iterate` iterations per
+  step.  {N: what the job would score at that speed}; no exchange is timed --
+  the gap to the driver's measured N-GPU value is communication + imbalance."""
+  import torch
+  from soda_amd import dist as sdist, runtime
+  out = {'1': value_1gpu}
+  cells = 1
+  for e in extent:
+    cells *= e
+  for n in (2, 4, 8):
+    try:
+      dry = runtime.resolve_options(stencil, options(fuses), extent)
+      fuse = 1
+      if dry.fuse:
+        fuse = max(dry.fuse)
+      ex = sdist.auto_exchange_every(stencil, extent, n, args.iterate,
+                                     multiple_of=fuse)
+      slab = sdist.Slab(stencil, extent, n, n // 2, ex)
+      lext = slab.local_extent
+      with runtime.Program(stencil, options(fuses), extent=lext,
+                           calibrate=True) as prog:
+        shape = tuple(lext[::-1])
+        a = [torch.rand(shape, device='cuda') for _ in stencil.input_names]
+        b = [torch.empty_like(t) for t in a]
+
+        def step():
+          done, cur, nxt = 0, a, b
+          while done < args.iterate:
+            k = min(ex, args.iterate - done)
+            prog.run_device([t.data_ptr() for t in nxt],
+                            [t.data_ptr() for t in cur], lext, iterate=k,
+                            stream=stream, origin=slab.origin,
+                            global_extent=slab.extent, keep=slab.keep)
+            cur, nxt = nxt, cur
+            done += k
+
+        step()
+        torch.cuda.synchronize()
+        ms = time_events(step, stream, 5)
+      out[str(n)] = cells * args.iterate / (ms * 1e-3)
+      out['slab_ms_%d' % n] = ms
+    except Exception as e:        # a rehearsal must not take the bench down
+      out[str(n)] = None
+      out['error_%d' % n] = str(e)[:160]
+  out['what'] = ('cells*iters/s of the whole job if every rank ran its slab '
+                 'at the speed of the middle rank\'s slab measured on this '
+                 'GPU; compute only')
+  return out
+
+
+def group_main(args):
+  """`--group`: one process, one host thread, N GPUs (or N virtual slabs on
+  GPU 0) through soda_hip_group_*: peer copies instead of RCCL."""
+  import numpy as np
+  import torch
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  n = args.gpus
+  have = torch.cuda.device_count()
+  if not args.virtual and have < n:
+    sys.stderr.write('bench.py: --group --gpus %d needs %d GPUs, %d visible '
+                     '(--virtual runs the slabs on one)\n' % (n, n, have))
+    sys.exit(2)
+  stencil = core.from_file(args.soda, iterate=args.iterate)
+  extent = list(args.extent)
+  if args.scaling == 'weak' and n > 1:
+    extent[-1] *= n
+  fuses = sorted({f for f in args.fuse if f >= 1}, reverse=True)
+  opts = lower.LowerOptions(strategy=args.strategy,
+                            fuse=tuple(f for f in fuses if f > 1),
+                            prefetch=args.prefetch, pipe=args.pipe)
+  devices = [0] * n if args.virtual else list(range(n))
+  rows = {}
+  for way in ((True, False) if args.overlap == 'auto' and n > 1 else
+              (args.overlap != 'off',)):
+    with runtime.Group(stencil, extent, devices, opts,
+                       exchange_every=args.exchange_every, overlap=way,
+                       calibrate=True) as group:
+      rng = np.random.default_rng(1234)
+      group.load({name: rng.random(tuple(extent[::-1]), dtype=np.float32)
+                  for name in stencil.input_names})
+      for _ in range(max(1, args.warmup)):
+        group.run()
+      group.synchronize()
+      enq = 0.0
+      t0 = time.perf_counter()
+      for _ in range(args.steps):
+        group.run()
+        enq += group.stats()['enqueue_ms']
+      group.synchronize()
+      dt = time.perf_counter() - t0
+      st = group.stats()
+      rows[way] = (dt, enq, st)
+  way = min(rows, key=lambda w: rows[w][0])
+  dt, enq, st = rows[way]
+  cells = 1
+  for e in extent:
+    cells *= e
+  table = stencil.symbol_table
+  print(json.dumps({
+      'metric': 'stencil cells*iters/s, %s %s iterate=%d' %
+                (stencil.app_name, 'x'.join(map(str, extent)), args.iterate),
+      'value': cells * args.iterate * args.steps / dt,
+      'unit': 'cells*iters/s', 'n_gpus': n, 'rccl_world': 0,
+      'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+      'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
+      'data': 'synthetic',
+      'config': {
+          'workload': '%s %s %s iterate=%d' % (
+              stencil.app_name, str(table[stencil.input_names[0]]),
+              'x'.join(map(str, extent)), args.iterate),
+          'transport': 'one process, soda_hip_group_*: peer copies'
+                       + (' between %d virtual slabs on GPU 0' % n
+                          if args.virtual else ' over xGMI'),
+          'overlap': bool(way),
+          'ms_per_step_by_overlap': {str(w): rows[w][0] / args.steps * 1e3
+                                     for w in rows},
+          'exchange_every': st['exchange_every'],
+          'exchanges_per_step': st['exchanges'],
+          'launches_per_step': st['launches'],
+          'split_passes_per_step': st['split_passes'],
+          'copy_bytes_per_step': st['copy_bytes'],
+          'host_enqueue_ms_per_step': enq / args.steps,
+      },
+  }))
 
 
 def launch_ranks(args) -> int:
@@ -148,6 +315,8 @@ def main():
   # a no-op when it is newer than its sources
   import __graft_entry__ as entry
   entry.build_library()
+  if args.group:
+    return group_main(args)
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(launch_ranks(args))
   import torch
@@ -238,10 +407,14 @@ def main():
       c_bufs.append(torch.empty_like(a_bufs[-1]))
   torch.cuda.synchronize()
 
-  def step_fn(dst, src, lext, iters):
+  def step_fn(dst, src, lext, iters, **kw):
+    kw.setdefault('keep', slab.keep)
     prog.run_device([t.data_ptr() for t in dst], [t.data_ptr() for t in src],
                     lext, iterate=iters, stream=stream, origin=slab.origin,
-                    global_extent=slab.extent, keep=slab.keep)
+                    global_extent=slab.extent, **kw)
+
+  hider = sdist.StreamOverlap(local_rank) if world > 1 else None
+  mode = {'overlap': world > 1 and args.overlap != 'off'}
 
   # A sustained iterated run: the input of a step is the output of the step
   # before it.  On N > 1 GPUs the ghost rows of that input are stale, so every
@@ -255,7 +428,8 @@ def main():
     cur = chain['cur']
     others = [x for x in pool if x is not cur]
     res = sdist.run(slab, cur, others[0], others[-1], step_fn, args.iterate,
-                    tdist, ghosts_fresh=chain['first'] or world == 1)
+                    tdist, ghosts_fresh=chain['first'] or world == 1,
+                    overlap=hider if mode['overlap'] else None)
     chain['first'] = False
     chain['cur'] = next(x for x in pool if x[0] is res[0])
     return res
@@ -327,12 +501,22 @@ def main():
   except Exception as e:  # a measurement aid must not take the bench down
     roofline['measured_copy_GBs'] = None
     roofline['measured_copy_error'] = str(e)[:200]
+  # PMC traffic is collected in separate rocprofv3 passes (tools/
+  # profile_round.sh) and kept in profiles/traffic.json under the content key
+  # of the kernel module it was measured on: a number taken on another build of
+  # the kernel -- same name, other code -- is dropped, not reported
+  kernel_key = runtime.source_key(prog.module.source)
+  roofline['kernel_key'] = kernel_key
   traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
   if os.path.exists(traffic_file):
     try:
       with open(traffic_file) as f:
         measured = json.load(f)
-      if kname in measured:
+      if kname in measured and measured[kname].get('kernel_key') != kernel_key:
+        roofline['traffic_dropped'] = (
+            'profiles/traffic.json holds %s for key %s; this run built key %s'
+            % (kname, measured[kname].get('kernel_key'), kernel_key))
+      elif kname in measured:
         roofline['traffic'] = measured[kname]['hbm_bytes_per_launch']
         roofline['traffic_source'] = measured[kname].get('source')
         insts = measured[kname].get('valu_wave_instructions_per_launch')
@@ -351,6 +535,26 @@ def main():
       pass
 
   launches_per_step = 0
+  overlap_trial = None
+  if world > 1 and args.overlap == 'auto':
+    # both ways, a few steps each; every rank must take the same decision
+    trial = {}
+    for way in (True, False, True, False):
+      mode['overlap'] = way
+      one_step()
+      torch.cuda.synchronize()
+      tdist.barrier()
+      t0 = time.perf_counter()
+      for _ in range(3):
+        one_step()
+      torch.cuda.synchronize()
+      t = torch.tensor([time.perf_counter() - t0], device=dev,
+                       dtype=torch.float64)
+      tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+      trial[way] = min(trial.get(way, 1e9), float(t.item()) / 3 * 1e3)
+    mode['overlap'] = trial[True] <= trial[False]
+    overlap_trial = {'overlapped_ms_per_step': trial[True],
+                     'serial_ms_per_step': trial[False]}
   for _ in range(args.warmup):
     one_step()
   torch.cuda.synchronize()
@@ -429,6 +633,10 @@ def main():
           # so on N > 1 GPUs every step opens with a halo exchange
           'exchanges_per_step': sdist.rounds(args.iterate, ex)
                                 if world > 1 else 0,
+          'overlap': bool(mode['overlap']),
+          **({'overlap_trial': overlap_trial} if overlap_trial else {}),
+          'transport': 'RCCL send/recv (torch.distributed, one rank per GPU)'
+                       if world > 1 else 'none',
           'ghost_rows_per_side': (slab.ghost_hi or slab.ghost_lo)
                                  if geo_world > 1 else 0,
           'ghost_row_fraction': (slab.rows - slab.own_rows) / float(slab.rows),
@@ -468,6 +676,9 @@ def main():
                            if roofline.get('measured_copy_GBs') else None},
       }
       prog1.close()
+    if not args.no_rehearsal and emulate <= 1:
+      result['rehearsed_scaling'] = rehearse(args, stencil, extent, fuses,
+                                             options, stream, value)
     if not args.no_cpu_baseline:
       result['cpu_baseline'] = cpu_baseline(stencil, extent, args.cpu_seconds)
 

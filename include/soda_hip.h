@@ -203,6 +203,10 @@ int soda_hip_compile(const char* source, const char* name,
                      const char* const* options, int32_t num_options,
                      void** code, size_t* code_size);
 void soda_hip_free_code(void* code);
+/* Version of the hiprtc that compiles (kernels built by another version may
+ * differ in registers and code size, which the launch geometry and the
+ * choice of peeled warm-up depend on: caches are keyed by it). */
+int soda_hip_compiler_version(int32_t* major, int32_t* minor);
 
 /* -- launch geometry (pure functions of the plan: no GPU, no program) ------- */
 /* What a run on `extent` would use: the tile of every kernel (num_kernels x

@@ -79,6 +79,20 @@ def add_arguments(parser) -> None:
                       dest='hip_no_xcd_swizzle',
                       help='do not remap blocks so neighbours share an XCD')
   parser.add_argument('--hip-device', type=int, dest='hip_device', default=0)
+  parser.add_argument('--hip-no-probe', action='store_true',
+                      dest='hip_no_probe',
+                      help='--hip-kernel / --hip-host: do not size the peeled '
+                      'warm-up by trial compilations (needs libsoda_hip.so + '
+                      'hiprtc); the emitted text is then the same on every '
+                      'box and toolchain')
+  parser.add_argument('--hip-gpus', type=int, dest='hip_gpus', default=1,
+                      metavar='N', help='--hip-backend / --hip-host: cut the '
+                      'grid into N slabs along the streamed dimension, one '
+                      'per GPU, halo exchange by peer copies '
+                      '(soda_hip_group_*)')
+  parser.add_argument('--hip-virtual', action='store_true', dest='hip_virtual',
+                      help='with --hip-gpus N: all N slabs on --hip-device '
+                      '(the whole schedule on one GPU)')
 
 
 def options_from_args(args: argparse.Namespace) -> lower.LowerOptions:
@@ -104,7 +118,9 @@ def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
     stencil = core.from_text(str(stencil))
   if args.hip_kernel is not None:
     from soda_amd import runtime
-    opts = runtime.resolve_options(stencil, options_from_args(args), None)
+    opts = runtime.resolve_options(stencil, options_from_args(args), None,
+                                   probe=not getattr(args, 'hip_no_probe',
+                                                     False))
     with tempfile.TemporaryFile(mode='w+') as tmp:
       tmp.write(lower.lower(stencil, opts).source)
       tmp.seek(0)
@@ -115,7 +131,9 @@ def print_code(stencil: core.Stencil, args: argparse.Namespace) -> None:
           shutil.copyfileobj(tmp, f)
   if getattr(args, 'hip_host', None) is not None:
     from soda_amd.codegen.hip import host
-    text = host.print_host(stencil, options_from_args(args), args.hip_extent)
+    text = host.print_host(stencil, options_from_args(args), args.hip_extent,
+                           gpus=max(1, int(getattr(args, 'hip_gpus', 1) or 1)),
+                           probe=not getattr(args, 'hip_no_probe', False))
     if args.hip_host == '-':
       sys.stdout.write(text)
     else:
@@ -162,16 +180,31 @@ def run(stencil: core.Stencil, args: argparse.Namespace) -> None:
     size = pstmt.size or (1,)
     inputs[pstmt.name] = np.indices(size).sum(axis=0).astype(
         pstmt.haoda_type.np_name)
-  prog = runtime.Program(stencil, options_from_args(args),
-                         device=args.hip_device, extent=extent)
-  t0 = time.time()
-  outputs = prog.run(inputs)
-  seconds = time.time() - t0
+  gpus = max(1, int(getattr(args, 'hip_gpus', 1) or 1))
+  extra = {}
+  if gpus > 1:
+    # one host thread, N GPUs: slabs along the streamed dimension
+    devices = ([args.hip_device] * gpus if getattr(args, 'hip_virtual', False)
+               else list(range(gpus)))
+    prog = runtime.Group(stencil, extent, devices, options_from_args(args))
+    t0 = time.time()
+    outputs = prog.run_host(inputs)
+    seconds = time.time() - t0
+    st = prog.stats()
+    extra = {'gpus': gpus, 'devices': devices,
+             'exchange_every': st['exchange_every'],
+             'exchanges': st['exchanges'], 'split_passes': st['split_passes']}
+  else:
+    prog = runtime.Program(stencil, options_from_args(args),
+                           device=args.hip_device, extent=extent)
+    t0 = time.time()
+    outputs = prog.run(inputs)
+    seconds = time.time() - t0
   cells = float(np.prod(extent)) * stencil.iterate
   print(json.dumps({
       'kernel': stencil.app_name, 'extent': extent,
       'iterate': stencil.iterate, 'seconds_incl_copies': seconds,
-      'cells_iters_per_s_incl_copies': cells / seconds,
+      'cells_iters_per_s_incl_copies': cells / seconds, **extra,
       'kernels': [k.name for k in prog.module.kernels],
       'checksum': {n: float(np.asarray(v, dtype=np.float64).sum())
                    for n, v in outputs.items()},

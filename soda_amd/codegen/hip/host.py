@@ -115,12 +115,65 @@ def emit_program(w, func: str, source_var: str, plan_func: str,
   w('}')
 
 
-def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
-               extent=None) -> str:
-  """C++ text of the host for `stencil` lowered with `opts` (chunks tuned for
-  `extent` if given; the kernels are correct for any extent)."""
+def emit_group(w, stencil: core.Stencil, gpus: int, source_var: str,
+               plan_func: str, label: str) -> None:
+  """`soda_hip_group_t* Group(extent)`: JIT + one slab per GPU, remade when
+  the extent changes."""
   from soda_amd import runtime
-  opts = runtime.resolve_options(stencil, opts, extent)
+  dim = stencil.dim
+  reach_lo, reach_hi = stencil.reach_along(dim - 1)
+  w('')
+  w('soda_hip_group_t* Group(const int32_t* extent) {')
+  w('  static soda_hip_group_t* group = nullptr;')
+  w('  static int32_t made_for[%d];' % dim)
+  w('  if (group && !memcmp(made_for, extent, sizeof made_for)) return group;')
+  w('  if (group) { soda_hip_group_destroy(group); group = nullptr; }')
+  w('  size_t len = 0;')
+  w('  for (const char* const* part = %s; *part; ++part) len += strlen(*part);'
+    % source_var)
+  w('  char* source = new char[len + 1];')
+  w('  source[0] = 0;')
+  w('  for (const char* const* part = %s; *part; ++part) strcat(source, *part);'
+    % source_var)
+  w('  const char* options[] = {%s};' % ', '.join(
+      '"%s"' % o for o in runtime.COMPILE_OPTIONS))
+  w('  void* code = nullptr;')
+  w('  size_t code_size = 0;')
+  w('  int rc = soda_hip_compile(source, "%s", options, %d, &code, '
+    '&code_size);' % (label, len(runtime.COMPILE_OPTIONS)))
+  w('  delete[] source;')
+  w('  if (rc) { Fail("compiling the kernels"); return nullptr; }')
+  w('  const soda_hip_plan_t plan = %s();' % plan_func)
+  w('  soda_hip_group_desc_t desc;')
+  w('  memset(&desc, 0, sizeof desc);')
+  w('  desc.num_slabs = %d;' % gpus)
+  w('  const char* virt = getenv("SODA_HIP_VIRTUAL_GPUS");')
+  w('  for (int s = 0; s < %d; ++s) desc.device[s] = virt && *virt == \'1\' ? 0 '
+    ': s;' % gpus)
+  w('  for (int d = 0; d < %d; ++d) desc.extent[d] = extent[d];' % dim)
+  w('  desc.reach_lo = %d;' % reach_lo)
+  w('  desc.reach_hi = %d;' % reach_hi)
+  w('  desc.iterate = %d;' % stencil.iterate)
+  w('  desc.exchange_every = 0;     // the library picks')
+  w('  desc.flags = SODA_HIP_GROUP_CALIBRATE | SODA_HIP_GROUP_THREADS;')
+  w('  rc = soda_hip_group_create(code, code_size, &plan, &desc, &group);')
+  w('  soda_hip_free_code(code);')
+  w('  if (rc) { Fail("loading the kernels"); group = nullptr; return nullptr; }')
+  w('  memcpy(made_for, extent, sizeof made_for);')
+  w('  return group;')
+  w('}')
+
+
+def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
+               extent=None, gpus: int = 1, probe: bool = True) -> str:
+  """C++ text of the host for `stencil` lowered with `opts` (chunks tuned for
+  `extent` if given; the kernels are correct for any extent).  `gpus` > 1: the
+  host cuts the grid into that many slabs, one per GPU, through
+  soda_hip_group_* -- still one blocking call in one host thread, like the
+  reference's (frt/host.py:319-322).  The environment variable
+  SODA_HIP_VIRTUAL_GPUS=1 puts all slabs on device 0 at run time."""
+  from soda_amd import runtime
+  opts = runtime.resolve_options(stencil, opts, extent, probe=probe)
   mod = lower.lower(stencil, opts)
   # register counts of the kernels as this toolchain compiles them: the
   # library sizes chunk lengths from them at run time
@@ -138,6 +191,7 @@ def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
   w('// (signature of reference src/soda/codegen/frt/host.py:62-88)')
   w('#include <cstdint>')
   w('#include <cstdio>')
+  w('#include <cstdlib>')
   w('#include <cstring>')
   w('#include "soda_hip.h"')
   w('')
@@ -148,7 +202,10 @@ def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
   w('')
   emit_fail(w, 'soda::app::%s' % app)
   w('')
-  emit_program(w, 'Program', 'kSodaSource', 'MakePlan', '%s.hip' % app)
+  if gpus > 1:
+    emit_group(w, stencil, gpus, 'kSodaSource', 'MakePlan', '%s.hip' % app)
+  else:
+    emit_program(w, 'Program', 'kSodaSource', 'MakePlan', '%s.hip' % app)
   w('}  // namespace')
   w('')
   # the operator
@@ -177,8 +234,9 @@ def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
       '(regenerate with --hip-vec)\\n");' % (app, opts.vec))
     w('    return 1;')
     w('  }')
-  w('  soda_hip_program_t* program = Program();')
-  w('  if (!program) return 1;')
+  if gpus == 1:
+    w('  soda_hip_program_t* program = Program();')
+    w('  if (!program) return 1;')
   ins = list(st.input_stmts) + list(st.param_stmts)
   w('  const soda_hip_host_tensor_t inputs[%d] = {' % len(ins))
   for stmt in ins:
@@ -211,9 +269,16 @@ def print_host(stencil: core.Stencil, opts: lower.LowerOptions,
         (o * dim + d, lo[d], o * dim + d, first, d, hi[d]))
       w('  if (valid_hi[%d] < valid_lo[%d]) valid_hi[%d] = valid_lo[%d];' %
         (o * dim + d, o * dim + d, o * dim + d, o * dim + d))
-  w('  if (soda_hip_run_host_box(program, inputs, outputs, %d, valid_lo, '
-    'valid_hi))' % st.iterate)
-  w('    return Fail("running");')
+  if gpus > 1:
+    w('  soda_hip_group_t* group = Group(var_%s_extent);' % first)
+    w('  if (!group) return 1;')
+    w('  if (soda_hip_group_run_host(group, inputs, outputs, %d, valid_lo, '
+      'valid_hi))' % st.iterate)
+    w('    return Fail("running");')
+  else:
+    w('  if (soda_hip_run_host_box(program, inputs, outputs, %d, valid_lo, '
+      'valid_hi))' % st.iterate)
+    w('    return Fail("running");')
   w('  return 0;')
   w('}')
   w('}  // namespace app')

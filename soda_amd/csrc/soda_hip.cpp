@@ -164,6 +164,16 @@ int soda_hip_compile(const char* source, const char* name,
 
 void soda_hip_free_code(void* code) { free(code); }
 
+int soda_hip_compiler_version(int32_t* major, int32_t* minor) {
+  if (!major || !minor) return fail(SODA_HIP_ERR_INVALID, "compiler_version: NULL");
+  int a = 0, b = 0;
+  if (hiprtcVersion(&a, &b) != HIPRTC_SUCCESS)
+    return fail(SODA_HIP_ERR_COMPILE, "hiprtcVersion failed");
+  *major = a;
+  *minor = b;
+  return SODA_HIP_OK;
+}
+
 static int check_plan(const soda_hip_plan_t* p);
 static int plan_geometry_c(const soda_hip_plan_t* plan, const int32_t* extent,
                            int32_t* tiles, float* pass_ns);

@@ -119,21 +119,107 @@ def exchange(slab: Slab, tensors: Sequence, dist_module, group=None) -> None:
       req.wait()
 
 
+class StreamOverlap:
+  """Runs a rank's halo exchanges on a stream of their own so that they hide
+  under the compute (GPU ranks; the counterpart of what soda_hip_group_* does
+  with peer copies inside one process).  `start` orders the exchange behind
+  the `sendable` event -- recorded by the previous interval's last pass as soon
+  as the rows the neighbours fetch are complete -- and returns the event the
+  refreshed ghosts are ready at; the engine passes both to
+  Program.run_device(ghosts=..., sends=..., ghosts_ready=..., sendable=...),
+  which launches the chunks next to the ghosts behind the one and fires the
+  other ahead of the interior of its last pass (soda_hip_run_device_slab).
+  RCCL's send/recv kernels run on RCCL's own stream; `req.wait()` only orders
+  the exchange stream behind them, the host does not block."""
+
+  def __init__(self, device: int = 0):
+    import torch
+    from soda_amd import runtime
+    self._torch = torch
+    self.comm = torch.cuda.Stream(device=device)
+    self.sendable = runtime.Event()
+    self.ready = [runtime.Event(), runtime.Event()]
+    self.turn = 0
+    self.recorded = False     # has a run recorded `sendable` yet?
+    self._lib = runtime.library()
+
+  def start(self, slab: Slab, tensors: Sequence, dist_module, group=None,
+            main_stream: int = 0):
+    """Enqueues the exchange of `tensors`' ghost rows; returns the raw event
+    handle to wait for (0 when there is nothing to exchange)."""
+    import ctypes
+    from soda_amd import runtime
+    if slab.world == 1:
+      return 0
+    torch = self._torch
+    comm_handle = ctypes.c_void_p(self.comm.cuda_stream)
+    if self.recorded:
+      runtime.check(self._lib.soda_hip_hipstream_wait_event(
+          comm_handle, self.sendable._h), 'hipstream_wait_event')
+    else:       # nothing recorded it yet: behind everything enqueued so far
+      self.comm.wait_stream(torch.cuda.current_stream())
+    ops = []
+    with torch.cuda.stream(self.comm):
+      for t in tensors:
+        for peer, (s0, s1), (r0, r1) in slab.messages():
+          if s1 > s0:
+            ops.append(dist_module.P2POp(dist_module.isend, t[s0:s1], peer,
+                                         group))
+          if r1 > r0:
+            ops.append(dist_module.P2POp(dist_module.irecv, t[r0:r1], peer,
+                                         group))
+      if ops:
+        for req in dist_module.batch_isend_irecv(ops):
+          req.wait()          # stream order only
+    ready = self.ready[self.turn]
+    self.turn ^= 1
+    ready.record(self.comm.cuda_stream)
+    return ready.handle()
+
+  def step_kwargs(self, slab: Slab, ghosts_ready: int):
+    """Keyword arguments for Program.run_device of the interval that follows
+    `start` (ghosts_ready = what it returned; 0: the ghosts are fresh)."""
+    self.recorded = True
+    k = slab.exchange_every
+    return dict(
+        keep=slab.keep,
+        ghosts=(slab.ghost_lo, slab.ghost_hi) if ghosts_ready else (0, 0),
+        sends=(slab.reach_hi * k if slab.rank > 0 else 0,
+               slab.reach_lo * k if slab.rank < slab.world - 1 else 0),
+        ghosts_ready=ghosts_ready, sendable=self.sendable.handle())
+
+
 def run(slab: Slab, src: Sequence, work_a: Sequence, work_b: Sequence,
-        step: Callable[[Sequence, Sequence, Tuple[int, ...], int], None],
-        iterate: int, dist_module, group=None, ghosts_fresh: bool = True):
+        step: Callable[..., None],
+        iterate: int, dist_module, group=None, ghosts_fresh: bool = True,
+        overlap: Optional[StreamOverlap] = None):
   """Advances the program `iterate` iterations.  `src` holds the inputs (own
-  rows + ghosts) and is never written; `work_a` / `work_b` are same-shaped
-  work arrays the state ping-pongs through (`work_b` is only touched when more
-  than one exchange interval is needed).  Returns the list that holds the
-  result.  `ghosts_fresh`: the ghosts of `src` already hold neighbour data
-  (true right after slicing them out of the global input)."""
+  rows + ghosts); `work_a` / `work_b` are same-shaped work arrays the state
+  ping-pongs through (`work_b` is only touched when more than one exchange
+  interval is needed).  Returns the list that holds the result.
+  `ghosts_fresh`: the ghosts of `src` already hold neighbour data (true right
+  after slicing them out of the global input); `src` is then never written.
+  With ghosts_fresh=False the run opens with an exchange that OVERWRITES the
+  ghost rows of `src` with the neighbours' rows (bench.py's chained steps rely
+  on exactly that): do not pass a view of data you need unchanged.
+  `overlap`: hide the exchanges under the compute; `step` is then called as
+  step(dst, src, extent, iters, **overlap.step_kwargs(...))."""
   cur, nxt = list(src), list(work_a)
   spare = list(work_b)
   done = 0
   fresh = ghosts_fresh
   while done < iterate:
     k = min(slab.exchange_every, iterate - done)
+    if overlap is not None:
+      token = 0 if fresh else overlap.start(slab, cur, dist_module, group)
+      step(nxt, cur, slab.local_extent, k, **overlap.step_kwargs(slab, token))
+      if done == 0:
+        cur, nxt = nxt, spare
+      else:
+        cur, nxt = nxt, cur
+      done += k
+      fresh = False
+      continue
     if not fresh:
       exchange(slab, cur, dist_module, group)
     step(nxt, cur, slab.local_extent, k)

@@ -172,6 +172,7 @@ API = {
         _pvp, ctypes.POINTER(ctypes.c_size_t)
     ]),
     'soda_hip_free_code': (None, [_vp]),
+    'soda_hip_compiler_version': (ctypes.c_int, [_pi32, _pi32]),
     'soda_hip_plan_geometry': (ctypes.c_int, [
         ctypes.POINTER(Plan), _pi32, _pi32, ctypes.POINTER(ctypes.c_float)
     ]),
@@ -329,14 +330,43 @@ def device_count() -> int:
   return n.value
 
 
+_compiler = None
+
+
+def compiler_version() -> str:
+  """'hiprtc <major>.<minor>' of the library that JIT-compiles, or 'unknown'
+  when it cannot be asked (no library built): part of every cache key, since
+  another compiler gives the same source other registers and code sizes."""
+  global _compiler
+  if _compiler is None:
+    try:
+      a, b = ctypes.c_int32(), ctypes.c_int32()
+      if library().soda_hip_compiler_version(ctypes.byref(a),
+                                             ctypes.byref(b)) == 0:
+        _compiler = 'hiprtc %d.%d' % (a.value, b.value)
+      else:
+        _compiler = 'unknown'
+    except (util.SodaError, OSError):
+      _compiler = 'unknown'
+  return _compiler
+
+
+def source_key(source: str, options: Sequence[str] = COMPILE_OPTIONS) -> str:
+  """Content hash of a kernel module as it is built: compiler version, compile
+  options, source text.  Names the code object in the JIT cache, and ties a
+  measurement (profiles/traffic.json) to the kernels it was taken on."""
+  return hashlib.sha256(
+      (compiler_version() + '\0' + '\0'.join(options) + '\0' +
+       source).encode()).hexdigest()[:24]
+
+
 def compile_source(source: str, name: str = 'soda.hip',
                    options: Sequence[str] = COMPILE_OPTIONS,
                    cache_dir: Optional[str] = None) -> bytes:
   """HIP text -> gfx950 code object, cached on disk by content hash.  Runs
   without a GPU (hiprtc), so `build()` can pre-compile on the CPU box."""
   cache_dir = CACHE_DIR if cache_dir is None else cache_dir
-  key = hashlib.sha256(
-      ('\0'.join(options) + '\0' + source).encode()).hexdigest()[:24]
+  key = source_key(source, options)
   path = os.path.join(cache_dir, '%s_%s.hsaco' % (name.replace('.', '_'), key))
   if os.path.exists(path):
     with open(path, 'rb') as f:
@@ -616,7 +646,8 @@ def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions',
               tile[k.tune['axis']] >= 8 * max(1, k.tune.get('warm') or 1)
     except util.SodaError:
       pass
-  key = hashlib.sha256(('peel2\0' + '\0'.join(COMPILE_OPTIONS) + '\0' +
+  key = hashlib.sha256(('peel3\0' + compiler_version() + '\0' +
+                        '\0'.join(COMPILE_OPTIONS) + '\0' +
                         repr(sorted(long_chunks.items())) + '\0' +
                         mod0.source).encode()).hexdigest()[:24]
   memo = os.path.join(CACHE_DIR, 'peel_%s.json' % key)
@@ -670,9 +701,14 @@ def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions',
 
 def resolve_options(stencil: core.Stencil,
                     opts: Optional['lower.LowerOptions'],
-                    extent: Optional[Sequence[int]]) -> 'lower.LowerOptions':
+                    extent: Optional[Sequence[int]],
+                    probe: bool = True) -> 'lower.LowerOptions':
   """A private copy of the caller's options with everything this module
-  decides filled in: the vector width for `extent`, the peel depths."""
+  decides filled in: the vector width for `extent`, the peel depths.  The peel
+  depths come from trial compilations (select_peel), which need the library
+  and hiprtc: with probe=False, or where they are not to be had (a text-only
+  use such as `sodac --hip-kernel` on a box without the library), the warm-up
+  is not peeled -- deterministic, correct, a few percent slower."""
   import copy
   out = copy.copy(opts) if opts is not None else lower.LowerOptions()
   if out.vec is None:
@@ -681,10 +717,13 @@ def resolve_options(stencil: core.Stencil,
     out.row_cells = int(extent[0])   # lets blocks cover whole rows (xshare)
   if out.peel is None and out.strategy in ('auto', 'march') and \
       lower.march_supported(stencil) is None:
-    try:
-      out.peel = select_peel(stencil, out, extent)
-    except util.SemanticError:
+    if not probe or os.environ.get('SODA_HIP_NO_PROBE'):
       out.peel = 0
+    else:
+      try:
+        out.peel = select_peel(stencil, out, extent)
+      except (util.SodaError, OSError):
+        out.peel = 0
   return out
 
 

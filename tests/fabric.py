@@ -18,7 +18,13 @@ class _Recv:
     self.q, self.tensor = q, tensor
 
   def wait(self) -> None:
-    self.tensor.copy_(self.q.get(timeout=TIMEOUT_S))
+    payload, ready = self.q.get(timeout=TIMEOUT_S)
+    if ready is not None:
+      # a device tensor copied on the SENDER's current stream: order the
+      # receiver's stream behind that copy (what RCCL's recv does by itself)
+      import torch
+      torch.cuda.current_stream().wait_event(ready)
+    self.tensor.copy_(payload)
 
 
 class _Done:
@@ -44,7 +50,12 @@ class Endpoint:
     reqs = []
     for op, tensor, peer in ops:      # sends first: they never block
       if op == self.isend:
-        self.fabric.q[(self.rank, peer)].put(tensor.clone())
+        payload, ready = tensor.clone(), None
+        if payload.is_cuda:
+          import torch
+          ready = torch.cuda.Event()
+          ready.record(torch.cuda.current_stream())
+        self.fabric.q[(self.rank, peer)].put((payload, ready))
         self.messages += 1
         self.bytes += tensor.numel() * tensor.element_size()
         reqs.append(_Done())

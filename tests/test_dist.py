@@ -299,6 +299,72 @@ def test_two_ranks_on_gpu_kernels(tmp_path, name, extent, iterate, every, fuse,
   assert np.array_equal(got[idx], want[idx])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,extent,iterate,every,fuse,world', [
+    ('jacobi2d.soda', (1024, 1600), 40, 12, (12, 4), 4),
+    ('jacobi2d.soda', (512, 480), 23, 4, (4,), 8),     # one pass per interval
+    ('heat3d.soda', (64, 48, 96), 9, 2, (2,), 4),
+])
+def test_exchange_hidden_under_the_compute(name, extent, iterate, every, fuse,
+                                           world):
+  """dist.StreamOverlap + Program.run_device(ghosts=..., sends=..., events):
+  every rank (a thread with a compute stream of its own; messages by
+  tests/fabric.py, which orders the receiver's stream behind the sender's copy
+  as RCCL does) runs its exchanges on a second stream while the rows that need
+  no fresh ghost compute; two chained runs, equal to the oracle bit for bit."""
+  import torch
+  import fabric
+  from soda_amd import core, dist as sdist, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  rng = np.random.default_rng(5)
+  field = rng.random(tuple(extent[::-1]), dtype=np.float32)
+  splits = []
+
+  def rank_fn(rank, endpoint):
+    slab = sdist.Slab(stencil, extent, world, rank, every)
+    prog = runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
+                           extent=slab.local_extent)
+    compute = torch.cuda.Stream()
+    with torch.cuda.stream(compute):
+      hider = sdist.StreamOverlap(0)
+      src = [torch.from_numpy(field[slab.begin:slab.end].copy()).cuda()]
+      work = [[torch.empty_like(src[0])] for _ in range(2)]
+
+      def step(dst, cur, lext, iters, **kw):
+        prog.run_device([t.data_ptr() for t in dst],
+                        [t.data_ptr() for t in cur], lext, iterate=iters,
+                        stream=compute.cuda_stream, origin=slab.origin,
+                        global_extent=slab.extent, **kw)
+        splits.append(prog.last_split())
+
+      res = sdist.run(slab, src, work[0], work[1], step, iterate, endpoint,
+                      overlap=hider)
+      # chained: the state's ghosts are stale, the run opens with an exchange
+      pool = [src] + work
+      others = [x for x in pool if x[0] is not res[0]]
+      res = sdist.run(slab, res, others[0], others[1], step, iterate,
+                      endpoint, ghosts_fresh=False, overlap=hider)
+      compute.synchronize()
+      hider.comm.synchronize()
+      own = res[0][slab.ghost_lo:slab.ghost_lo + slab.own_rows].cpu().numpy()
+    prog.close()
+    return own, endpoint.messages
+
+  results = fabric.run_ranks(world, rank_fn)
+  got = np.concatenate([r[0] for r in results], axis=0)
+  rounds = sdist.rounds(iterate, every)
+  assert results[0][1] == 2 * rounds - 1 and results[1][1] == 2 * (2 * rounds - 1)
+  assert sum(splits) > 0, 'no pass was ever split'
+  again = core.from_file(soda_path(name), iterate=2 * iterate)
+  want = c_oracle.COracle(again).run({again.input_names[0]: field})[
+      again.output_names[0]]
+  lo, hi = again.valid_box(extent)
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  assert np.array_equal(got[idx], want[idx])
+
+
 def test_thin_slab_is_refused_on_every_rank():
   """n % world != 0: ranks differ by one row.  The halo check judges the
   thinnest slab, so either every rank raises or none does (a rank that passed

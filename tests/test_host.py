@@ -51,6 +51,41 @@ def test_generated_host_runs_without_python(built, tmp_path):
       run.stdout + run.stderr)
 
 
+def test_generated_multi_gpu_host_compiles(built, tmp_path):
+  """--hip-gpus N: the same operator signature, soda_hip_group_* behind it."""
+  src = _generate(tmp_path, 'heat3d.soda', '--iterate', '9', '--hip-gpus', '4',
+                  '--hip-fuse', '2')
+  text = open(src).read()
+  assert 'desc.num_slabs = 4;' in text and 'desc.reach_lo = 1;' in text
+  assert 'soda_hip_group_run_host(group, inputs, outputs, 9,' in text
+  assert 'soda_hip_run_host_box' not in text
+  subprocess.run(['g++', '-std=c++17', '-Wall', '-Werror', '-c', src,
+                  '-I', os.path.join(ROOT, 'include'), '-o',
+                  os.path.join(str(tmp_path), 'host.o')], check=True)
+
+
+@pytest.mark.gpu
+def test_generated_multi_gpu_host_runs_without_python(built, tmp_path):
+  """One blocking C++ call, four slabs with halo exchanges behind it (virtual
+  devices on the one GPU): the p + q + r field is a fixed point of heat3d bit
+  for bit on the valid box, the rest of the caller's array untouched."""
+  src = _generate(tmp_path, 'heat3d.soda', '--iterate', '9', '--hip-gpus', '4',
+                  '--hip-fuse', '2', '--hip-extent', '64', '48', '96')
+  exe = os.path.join(str(tmp_path), 'heat3d_group')
+  libdir = os.path.join(ROOT, 'soda_amd')
+  subprocess.run(['g++', '-std=c++17', '-O1', src,
+                  os.path.join(ROOT, 'tests', 'host', 'heat3d_group_main.cpp'),
+                  '-I', os.path.join(ROOT, 'include'), '-L', libdir,
+                  '-lsoda_hip', '-Wl,-rpath,' + libdir, '-o', exe], check=True)
+  env = dict(os.environ)
+  env['LD_LIBRARY_PATH'] = '/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
+  env['SODA_HIP_VIRTUAL_GPUS'] = '1'
+  run = subprocess.run([exe], capture_output=True, text=True, env=env,
+                       timeout=300)
+  assert run.returncode == 0 and run.stdout.startswith('OK'), (
+      run.stdout + run.stderr)
+
+
 def _generate_wire(tmp_path, soda):
   out = os.path.join(str(tmp_path), 'wire.cpp')
   subprocess.run([sys.executable, '-m', 'soda_amd.sodac', soda_path(soda),
