@@ -255,7 +255,11 @@ int soda_hip_run_device_window(soda_hip_program_t* program,
  * cells below and `reach_hi` above a cell along that dimension.  Every pass is
  * then launched only on the rows the iterations still to come can carry into
  * the kept range (a cone that narrows pass by pass); outside it the outputs
- * are unspecified.  A side with keep_lo = 0 (keep_hi = extent) is never
+ * are unspecified -- NOT "unchanged": the last pass still stores up to
+ * fused_iters x reach rows on either side of [keep_lo, keep_hi), computed with
+ * zeros where the launch ended, and leaves the rows beyond those as they
+ * were, so a caller that reuses the output arrays sees a mix of stale and
+ * wrong rows there.  A side with keep_lo = 0 (keep_hi = extent) is never
  * trimmed.  The reference has no counterpart: its host tiles with a
  * replicated halo and recomputes all of it (frt/host.py:124-128). */
 int soda_hip_run_device_cone(soda_hip_program_t* program,

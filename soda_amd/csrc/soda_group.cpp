@@ -70,7 +70,9 @@ struct Slab {
 // three streams and two devices, and two passes launched in two parts each.
 const double kXferLatencyNs = 20000.0;
 const double kXferBytesPerNs = 50.0;
-const double kSplitNs = 10000.0;
+// (measured: a pass launched in two parts costs ~17 us more than whole, two
+// per exchange -- profiles/r03_slab_overlap.jsonl)
+const double kSplitNs = 34000.0;
 
 }  // namespace
 

@@ -1512,9 +1512,14 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
   }
   std::vector<void*> dout(d.num_outputs);
   for (int o = 0; o < d.num_outputs; ++o) {
-    if (int rc = ensure(s->dense_out[o],
-                        (size_t)n * d.elem_size[d.num_inputs + o]))
-      return rc;
+    const size_t bytes = (size_t)n * d.elem_size[d.num_inputs + o];
+    const void* before = s->dense_out[o].ptr;
+    if (int rc = ensure(s->dense_out[o], bytes)) return rc;
+    // new memory: the dense view drops the partial last row, whose bytes would
+    // otherwise reach the caller's banks uninitialised through wire_<out>
+    if (s->dense_out[o].ptr != before)
+      HIP_TRY(hipMemsetAsync(s->dense_out[o].ptr, 0, s->dense_out[o].bytes,
+                             static_cast<hipStream_t>(hip_stream)));
     dout[o] = s->dense_out[o].ptr;
   }
   // 2. the program.  Dense view: the stream is an array of extent (tile...,
