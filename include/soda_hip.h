@@ -363,6 +363,14 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
 int soda_hip_program_calibrate(soda_hip_program_t* program,
                                const int32_t* extent, int32_t launches,
                                void* stream);
+/* Programs calibrate by themselves: the first run of more than one iteration
+ * on an extent (any run entry; only the extent the call names, not the
+ * trimmed sub-extents of cone runs) first times the passes on it -- it
+ * synchronises `stream` once and costs a few milliseconds -- so that every
+ * caller, the generated C++ host included, is scheduled by the clock, not by
+ * the model (whose error is ~9 % per pass).  on = 0 turns that off for a
+ * program; the environment variable SODA_HIP_NO_CALIBRATE=1 for all. */
+int soda_hip_program_set_auto_calibrate(soda_hip_program_t* program, int on);
 /* Time of one launch of every pass on `extent` in ns (num_passes values):
  * measured if calibrated (*measured = 1), else the model's. */
 int soda_hip_program_pass_times(soda_hip_program_t* program,

@@ -83,6 +83,10 @@ struct soda_hip_program {
   int32_t last_split = 0;    // passes of the last run launched in two parts
   int64_t last_rows = 0;     // cells along the last dimension, summed over passes
   void* debug = nullptr;     // time-stamp buffer of diagnostic builds
+  // time every pass on an extent the first time it is run (a few ms, once):
+  // on unless SODA_HIP_NO_CALIBRATE is set or the caller turns it off
+  bool auto_calibrate = true;
+  bool calibrating = false;
   // measured time of one launch of every pass, per extent (calibrate)
   std::map<soda_detail::ExtentKey, std::vector<double>> measured;
   std::map<soda_detail::ExtentKey, soda_detail::ExtentPlan> extents;

@@ -233,6 +233,7 @@ API = {
     'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),
     'soda_hip_program_set_debug_buffer': (ctypes.c_int, [_vp, _vp]),
     'soda_hip_program_calibrate': (ctypes.c_int, [_vp, _pi32, _i32, _vp]),
+    'soda_hip_program_set_auto_calibrate': (ctypes.c_int, [_vp, ctypes.c_int]),
     'soda_hip_program_schedule': (ctypes.c_int, [_vp, _pi32, _i32, _pi32]),
     'soda_hip_program_pass_times': (ctypes.c_int, [
         _vp, _pi32, ctypes.POINTER(ctypes.c_float), _pi32
@@ -395,10 +396,12 @@ def compile_source(source: str, name: str = 'soda.hip',
   return blob
 
 
-# ns of SIMD issue time per vector instruction of a marching kernel's row step:
-# the fused kernels sustain 3.2-3.8 cycles per wave64 instruction at ~2.3 GHz
-# with their lane shifts (profiles/)
-NS_PER_VALU_OP = 1.4
+# ns of SIMD issue time per vector instruction of a marching kernel's row step,
+# fitted with the other constants of the library's time model (soda_hip.cpp
+# "Constants of the launch-time model", tools/fit_model.py); the fused kernels
+# sustain 3.2-3.8 cycles per wave64 instruction at ~2.3 GHz with their lane
+# shifts (profiles/)
+NS_PER_VALU_OP = 1.187
 
 
 def make_plan(mod: lower.Module,
@@ -733,7 +736,11 @@ class Program:
   def __init__(self, stencil: core.Stencil,
                opts: Optional[lower.LowerOptions] = None, device: int = 0,
                extent: Optional[Sequence[int]] = None,
-               calibrate: bool = False):
+               calibrate: Optional[bool] = None):
+    """`calibrate`: True -- time the passes on `extent` now; None (default) --
+    the library does it by itself on the first run of an extent (a few ms,
+    once; soda_hip_program_set_auto_calibrate); False -- never: runs are
+    scheduled by the model."""
     self.stencil = stencil
     self.opts = resolve_options(stencil, opts, extent)   # never the caller's
     self.device = device
@@ -753,6 +760,9 @@ class Program:
                                           ctypes.byref(self.plan), device,
                                           ctypes.byref(self._handle)),
         'loading `%s` on GPU %d' % (stencil.app_name, device))
+    if calibrate is False:
+      check(self._lib.soda_hip_program_set_auto_calibrate(self._handle, 0),
+            'set_auto_calibrate')
     if calibrate and extent is not None:
       self.calibrate(extent)
 

@@ -952,10 +952,11 @@ def test_calibrated_schedule(built):
   inputs = _inputs(stencil, extent, seed=4)
   want = c_oracle.COracle(stencil).run(inputs)['t0']
   with runtime.Program(stencil, lower.LowerOptions(fuse=(12, 8, 4)),
-                       extent=extent) as prog:
+                       extent=extent, calibrate=False) as prog:
     model, measured = prog.pass_times(extent)
     assert not measured and set(model) == {12, 8, 4, 1}
     before = prog.run(inputs)['t0']
+    assert not prog.pass_times(extent)[1]     # told not to: still the model
     times = prog.calibrate(extent)
     assert prog.pass_times(extent)[1]
     assert all(0.5 < v < 5000 for v in times.values()), times
@@ -967,3 +968,41 @@ def test_calibrated_schedule(built):
   idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
   assert np.array_equal(before[idx], want[idx])
   assert np.array_equal(after, before)
+  # by default a program calibrates by itself on the first run of an extent
+  with runtime.Program(stencil, lower.LowerOptions(fuse=(12, 8, 4)),
+                       extent=extent) as prog:
+    assert not prog.pass_times(extent)[1]
+    auto = prog.run(inputs)['t0']
+    assert prog.pass_times(extent)[1]
+    assert not prog.pass_times((1024, 608))[1]      # that extent only
+  assert np.array_equal(auto, before)
+
+
+@pytest.mark.parametrize('name,extent,fuse,iterate', [
+    ('jacobi2d.soda', (8192, 8192), (12, 8, 4), 100),
+    ('jacobi2d.soda', (8192, 1224), (12, 8, 4), 100),   # slab of an 8-GPU run
+    ('jacobi2d.soda', (8192, 2248), (12, 8, 4), 100),
+    ('heat3d.soda', (512, 512, 80), (2,), 8),
+])
+def test_model_schedule_is_close_to_the_calibrated_one(built, name, extent,
+                                                       fuse, iterate):
+  """The constants of the library's time model are fits (soda_hip.cpp,
+  tools/fit_model.py); they decide the schedule of every caller that turns
+  calibration off and the exchange interval of a slab group.  Priced with the
+  MEASURED pass times, the schedule the model picks must cost at most 10 %
+  more than the one the clock picks."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  with runtime.Program(stencil, lower.LowerOptions(fuse=fuse), extent=extent,
+                       calibrate=False) as prog:
+    by_model = prog.schedule(extent, iterate)
+    model_us, _ = prog.pass_times(extent)
+    clock_us = prog.calibrate(extent, launches=8)
+    by_clock = prog.schedule(extent, iterate)
+  cost = lambda sched: sum(clock_us[t] * c for t, c in sched.items())
+  assert cost(by_model) <= 1.10 * cost(by_clock), (by_model, by_clock,
+                                                  model_us, clock_us)
+  # and no pass is modelled off by more than a third
+  for t, us in clock_us.items():
+    assert 0.67 < model_us[t] / us < 1.5, (t, model_us, clock_us)

@@ -35,7 +35,7 @@ def main():
     row = dict(extent=extent, passes={})
     st_all = core.from_file(args.soda, iterate=args.iterate)
     with runtime.Program(st_all, lower.LowerOptions(fuse=tuple(args.fuse)),
-                         extent=extent) as prog:
+                         extent=extent, calibrate=False) as prog:
       tiles, model = prog.geometry(extent)
       row['schedule'] = prog.schedule(extent, args.iterate)
       row['model_total_us'] = sum(model[t] * c for t, c in row['schedule'].items())
@@ -56,7 +56,7 @@ def main():
     for t in sorted(set(args.fuse) | {1}, reverse=True):
       st = core.from_file(args.soda, iterate=t * args.launches)
       with runtime.Program(st, lower.LowerOptions(fuse=(t,) if t > 1 else ()),
-                           extent=extent) as prog:
+                           extent=extent, calibrate=False) as prog:
         tiles, model = prog.geometry(extent)
 
         def go():
@@ -72,9 +72,18 @@ def main():
             go()
           b.record(stream)
           best = min(best, a.elapsed_ms(b) / args.reps / args.launches * 1e3)
-        name = [k.name for k in prog.module.kernels if k.tune and k.tune.get('fused') == t][0]
+        kk = [k for k in prog.module.kernels if k.tune and k.tune.get('fused') == t][0]
+        name = kk.name
+        idx = prog.module.kernels.index(kk)
+        d = prog.plan.kernels[idx]
         row['passes'][t] = dict(model_us=round(model[t], 1), measured_us=round(best, 1),
-                                tile=tiles[name], vgpr=prog.resources[name]['vgpr'])
+                                tile=tiles[name], vgpr=prog.resources[name]['vgpr'],
+                                desc=dict(warm=d.warm, warm_saved=d.warm_saved,
+                                          step_ns=d.step_ns, lanes=d.lane_redundancy,
+                                          bytes_per_cell=d.bytes_per_cell,
+                                          block=list(d.block), vec=d.vec,
+                                          waves_along=d.waves_along, pipe=d.pipe,
+                                          strip_cells=kk.tile[0]))
     print(json.dumps(row), flush=True)
     if args.out:
       with open(args.out, 'a') as f:
