@@ -322,3 +322,94 @@ int kat_rebalanced_sum(const float* in, float* out, int32_t w, int32_t h,
   free(part);
   return 0;
 }
+
+/* ---- the reference's two remaining 3-D programs, by hand from the DSL text --
+ * Same box rule as above (frt/host.py:565-577): every tensor lives on the box
+ * of its window relative to the program inputs and is zero outside it.  With
+ * these two, every program of the reference's corpus has a pin that never
+ * touches this repo's parser, IR or generators. */
+
+/* reference tests/src/jacobi3d.soda:5-11 (iterate: 2 as shipped)
+ *   t0(0,0,0) = (t1(0,0,0) + t1(1,0,0) + t1(-1,0,0) + t1(0,1,0) + t1(0,-1,0)
+ *                + t1(0,0,1) + t1(0,0,-1)) * 0.142857142f
+ * the sum left to right as written; iteration r lives on [r, n - r)^3. */
+int kat_jacobi3d(const float* in, float* out, int32_t nx, int32_t ny,
+                 int32_t nz, int32_t iterate) {
+  const ptrdiff_t sy = nx, sz = (ptrdiff_t)nx * ny;
+  const size_t cells = (size_t)sz * nz;
+  float* tmp[2] = {calloc(cells, sizeof(float)), calloc(cells, sizeof(float))};
+  if (!tmp[0] || !tmp[1]) return 1;
+  const float* src = in;
+  memset(out, 0, cells * sizeof(float));
+  for (int32_t it = 0; it < iterate; ++it) {
+    float* dst = it == iterate - 1 ? out : tmp[it & 1];
+    const int32_t r = it + 1;
+    for (int32_t z = r; z < nz - r; ++z)
+      for (int32_t y = r; y < ny - r; ++y)
+        for (int32_t x = r; x < nx - r; ++x) {
+          const float* c = src + z * sz + y * sy + x;
+          dst[z * sz + y * sy + x] =
+              (c[0] + c[1] + c[-1] + c[sy] + c[-sy] + c[sz] + c[-sz]) *
+              0.142857142f;
+        }
+    src = dst;
+  }
+  free(tmp[0]);
+  free(tmp[1]);
+  return 0;
+}
+
+/* reference tests/src/denoise3d.soda:8-29: two inputs f, u; locals diff_u
+ * (u - u(0,-1,0), box y >= 1), diff_d (y < ny-1), diff_l (x >= 1), diff_r
+ * (x < nx-1), diff_i (u - u(0,0,-1), z >= 1), diff_o (z < nz-1); g on
+ * [1, n-1)^3 (it reads all six where each is defined); r0, r1 everywhere;
+ * output on [2, n-2)^3.  `1.0f/0.03f` is one float constant; `sqrt` of a float
+ * is the float overload; sums and products associate left to right as written:
+ *   g  = 1.0f / sqrt(0.00005f + du*du + dd*dd + dl*dl + dr*dr + di*di + do*do)
+ *   r0 = u * f * (1.0f/0.03f)
+ *   r1 = (r0*(2.38944f + r0*(0.950037f + r0)))
+ *        / (4.65314f + r0*(2.57541f + r0*(1.48937f + r0)))
+ *   output = (u + 5.0f*(u(1,0,0)*g(1,0,0) + u(-1,0,0)*g(-1,0,0)
+ *             + u(0,1,0)*g(0,1,0) + u(0,-1,0)*g(0,-1,0) + u(0,0,1)*g(0,0,1)
+ *             + u(0,0,-1)*g(0,0,-1) + (1.0f/0.03f)*f*r1))
+ *          / (1.0f + 5.0f*(g(1,0,0) + g(-1,0,0) + g(0,1,0) + g(0,-1,0)
+ *             + g(0,0,1) + g(0,0,-1) + (1.0f/0.03f))) */
+int kat_denoise3d(const float* f, const float* u, float* out, int32_t nx,
+                  int32_t ny, int32_t nz) {
+  const ptrdiff_t sy = nx, sz = (ptrdiff_t)nx * ny;
+  const size_t cells = (size_t)sz * nz;
+  float* g = calloc(cells, sizeof(float));
+  float* r1 = calloc(cells, sizeof(float));
+  if (!g || !r1) return 1;
+  const float k = 1.0f / 0.03f;
+  memset(out, 0, cells * sizeof(float));
+  for (int32_t z = 1; z < nz - 1; ++z)
+    for (int32_t y = 1; y < ny - 1; ++y)
+      for (int32_t x = 1; x < nx - 1; ++x) {
+        const ptrdiff_t i = z * sz + y * sy + x;
+        const float du = u[i] - u[i - sy], dd = u[i] - u[i + sy];
+        const float dl = u[i] - u[i - 1], dr = u[i] - u[i + 1];
+        const float di = u[i] - u[i - sz], dq = u[i] - u[i + sz];
+        g[i] = 1.0f / sqrtf(0.00005f + du * du + dd * dd + dl * dl + dr * dr +
+                            di * di + dq * dq);
+      }
+  for (size_t i = 0; i < cells; ++i) {
+    const float r0 = u[i] * f[i] * k;
+    r1[i] = (r0 * (2.38944f + r0 * (0.950037f + r0))) /
+            (4.65314f + r0 * (2.57541f + r0 * (1.48937f + r0)));
+  }
+  for (int32_t z = 2; z < nz - 2; ++z)
+    for (int32_t y = 2; y < ny - 2; ++y)
+      for (int32_t x = 2; x < nx - 2; ++x) {
+        const ptrdiff_t i = z * sz + y * sy + x;
+        out[i] = (u[i] + 5.0f * (u[i + 1] * g[i + 1] + u[i - 1] * g[i - 1] +
+                                 u[i + sy] * g[i + sy] + u[i - sy] * g[i - sy] +
+                                 u[i + sz] * g[i + sz] + u[i - sz] * g[i - sz] +
+                                 k * f[i] * r1[i])) /
+                 (1.0f + 5.0f * (g[i + 1] + g[i - 1] + g[i + sy] + g[i - sy] +
+                                 g[i + sz] + g[i - sz] + k));
+      }
+  free(g);
+  free(r1);
+  return 0;
+}

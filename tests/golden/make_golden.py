@@ -4,9 +4,10 @@
 The reference cannot be run here, so these vectors come from
 this repo's CPU oracle AFTER it passed the closed-form KATs and the
 three-restatement agreement tests in tests/test_oracle.py; they freeze that
-behaviour so later rounds cannot drift silently.  For jacobi2d, blur, heat3d
-and skew2d the expected outputs are produced by the HAND-WRITTEN C kernels in
-oracle/kat_kernels.c (independent of this repo's parser and generators)."""
+behaviour so later rounds cannot drift silently.  For jacobi2d, blur, heat3d,
+skew2d, jacobi3d and denoise3d the expected outputs are produced by the
+HAND-WRITTEN C kernels in oracle/kat_kernels.c (independent of this repo's
+parser and generators)."""
 import ctypes
 import os
 import subprocess
@@ -88,6 +89,22 @@ def main():
     np.savez_compressed(os.path.join(HERE, tag + '.npz'), iterate=st.iterate,
                         **{'in_' + k: v for k, v in ins.items()},
                         **{'out_' + k: v for k, v in outs.items()})
+
+
+  # the reference's two 3-D programs left (round 3): expected outputs from the
+  # HAND-WRITTEN nests in oracle/kat_kernels.c.  Own seed again.
+  rng3 = np.random.default_rng(20260103)
+  a = rng3.random((12, 14, 20), dtype=np.float32)
+  out = np.empty_like(a)
+  kat.kat_jacobi3d(ptr(a), ptr(out), 20, 14, 12, 2)
+  np.savez_compressed(os.path.join(HERE, 'jacobi3d.npz'), iterate=2, in_t1=a,
+                      out_t0=out)
+  f = rng3.random((12, 14, 20), dtype=np.float32)
+  u = rng3.random((12, 14, 20), dtype=np.float32)
+  out = np.empty_like(f)
+  kat.kat_denoise3d(ptr(f), ptr(u), ptr(out), 20, 14, 12)
+  np.savez_compressed(os.path.join(HERE, 'denoise3d.npz'), iterate=1, in_f=f,
+                      in_u=u, out_output=out)
 
 
 if __name__ == '__main__':

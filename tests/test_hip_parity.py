@@ -311,6 +311,33 @@ def test_iterated_multi_stage_and_3d(built, name, iterate, fuse):
   _check(stencil, extent, lower.LowerOptions(fuse=fuse), oracle='c')
 
 
+@pytest.mark.parametrize('iterate,extent', [(2, (40, 12, 10, 9)),
+                                            (3, (68, 9, 11, 12)),
+                                            (1, (4, 5, 3, 6))])
+def test_four_dimensional_program(built, iterate, extent):
+  """The reference's coordinate sets are four deep (ref src/soda/util.py:4-6)
+  and SODA_HIP_MAX_DIM is 4: a 4-D program (tests/golden/heat4d.soda, a
+  9-point star whose coefficients are powers of two that sum to 1) on the
+  `direct` kernels, against both oracles and the closed form -- the field
+  p + q + r + s is a fixed point bit for bit on the valid box."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import numpy_oracle
+  stencil = core.from_file(soda_path('heat4d.soda'), iterate=iterate)
+  assert stencil.dim == 4
+  _check(stencil, extent, lower.LowerOptions(), oracle='c')
+  ramp = np.indices(extent[::-1]).sum(axis=0).astype(np.float32)
+  with runtime.Program(stencil, lower.LowerOptions(), extent=extent) as prog:
+    assert all('direct' in k.name for k in prog.module.kernels)
+    got = prog.run({'in': ramp})['out']
+  lo, hi = stencil.valid_box(extent)
+  assert lo == (iterate,) * 4
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  assert np.array_equal(got[idx], ramp[idx])
+  want = numpy_oracle.run(stencil, {'in': ramp})['out']
+  assert np.array_equal(got[idx], want[idx])
+
+
 @pytest.mark.parametrize('name,extent,fuse', [
     ('coupled2d.soda', (300, 90), (2,)),     # 2 inputs -> 2 outputs, iterate 3
     ('coupled2d.soda', (300, 90), ()),
@@ -545,10 +572,31 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
       assert np.array_equal(got[o], ref[o]), o
     else:
       assert np.array_equal(got[o][idx], ref[o][idx]), o
-  if layout.tiles > 1:
-    return       # the reference host's own tile strides disagree (frt_layout)
   want = numpy_oracle.run(stencil, inputs)
   assert all(h > l for l, h in zip(lo, hi))
+  if layout.tiles > 1:
+    # Known upstream defect: the reference host scatters
+    # tile t from column t * (tile - kStencilDim) (frt/host.py:224-228) but
+    # gathers it to column t * (tile - kStencilDim + 1) (:389-393), so from
+    # the second tile on the caller gets results one column further off per
+    # tile.  Where both maps agree -- tile index 0 in every tiled dimension --
+    # the n-D oracle IS comparable: the cells tile 0 delivers.
+    window = stencil.stencil_window_points(stencil.output_names[0])
+    first = []
+    for d in range(stencil.dim - 1):
+      off = -min(p[d] for p in window)
+      sdim = max(p[d] for p in window) + off + 1
+      first.append((max(lo[d], off),
+                    min(hi[d], stencil.tile_size[d] - max(0, sdim - 1 - off))))
+    first.append((lo[-1], hi[-1]))
+    assert all(b > a for a, b in first)
+    idx0 = tuple(slice(a, b) for a, b in first[::-1])
+    for o in stencil.output_names:
+      assert got[o][idx0].size and np.array_equal(got[o][idx0], want[o][idx0]), o
+    # ... and beyond it the defect is really there (or this comment is stale)
+    o = stencil.output_names[0]
+    assert not np.array_equal(got[o][idx], want[o][idx])
+    return
   for o in stencil.output_names:
     assert np.array_equal(got[o][idx], want[o][idx]), o
     if len(stencil.output_names) == 1:
@@ -828,6 +876,8 @@ def test_scheduler_picks_the_cheapest_pass_mix(built):
     ('skew2d', 'skew2d.soda', None),
     ('sobel2d', 'sobel2d.soda', None),
     ('denoise2d', 'denoise2d.soda', None),
+    ('jacobi3d', 'jacobi3d.soda', None),       # hand-written nests, round 3
+    ('denoise3d', 'denoise3d.soda', None),
     ('jacobi2d_preserve', 'jacobi2d.soda', 'preserve'),
     ('heat3d_preserve', 'heat3d.soda', 'preserve'),
     ('conv2d', 'conv2d.soda', None),

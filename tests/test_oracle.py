@@ -173,7 +173,8 @@ def test_min_max_calls_and_sqrt():
 
 
 @pytest.mark.parametrize('name', ['jacobi2d', 'blur', 'heat3d', 'skew2d',
-                                  'sobel2d', 'denoise2d'])
+                                  'sobel2d', 'denoise2d', 'jacobi3d',
+                                  'denoise3d'])
 def test_committed_golden_vectors(name):
   """tests/golden/*.npz, written by tests/golden/make_golden.py."""
   from oracle import numpy_oracle
@@ -382,11 +383,25 @@ def _corpus_kat(kat, name, rng):
     out = np.empty_like(a)
     assert kat.kat_xcorr(_ptr(a), _ptr(out), w, h) == 0
     return {'input': a}, {'tmp3': out}
+  shape3 = (14, 18, 22)           # 22 cells along dim 0, 14 planes
+  nz, ny, nx = shape3
+  if name == 'jacobi3d':
+    a = rng.random(shape3, dtype=np.float32)
+    out = np.empty_like(a)
+    assert kat.kat_jacobi3d(_ptr(a), _ptr(out), nx, ny, nz, 2) == 0
+    return {'t1': a}, {'t0': out}
+  if name == 'denoise3d':
+    f = rng.random(shape3, dtype=np.float32)
+    u = rng.random(shape3, dtype=np.float32)
+    out = np.empty_like(f)
+    assert kat.kat_denoise3d(_ptr(f), _ptr(u), _ptr(out), nx, ny, nz) == 0
+    return {'f': f, 'u': u}, {'output': out}
   raise KeyError(name)
 
 
 @pytest.mark.parametrize('name', ['sobel2d', 'seidel2d', 'denoise2d',
-                                  'erosion', 'xcorr'])
+                                  'erosion', 'xcorr', 'jacobi3d',
+                                  'denoise3d'])
 def test_corpus_against_hand_written_kernels(kat, name):
   """Front-end + both generated oracles against an independent reading of the
   program text, bit for bit on the valid box; zero outside it."""
