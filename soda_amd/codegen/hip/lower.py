@@ -79,7 +79,22 @@ class LowerOptions:
                counted_waits: Optional[bool] = None, stamps: bool = False,
                peel=None, align_lanes: Optional[int] = None,
                xshare: Optional[bool] = None,
-               row_cells: Optional[int] = None):
+               row_cells: Optional[int] = None,
+               windows: Optional[bool] = None,
+               inline: Optional[bool] = None):
+    # locals read only at the cell being computed are folded into their
+    # consumers (optimization/pointwise.py): denoise3d is 4 tensors instead
+    # of 10.  SODA_HIP_INLINE=0/1 overrides for A/B runs
+    if inline is None:
+      inline = os.environ.get('SODA_HIP_INLINE', '1') != '0'
+    self.inline = inline
+    # long integer window reductions (erosion's 19-tap min, xcorr's 19-tap
+    # sums) as chains of power-of-two windows: 6 instead of 18 operations per
+    # cell, bit-exact (optimization/windows.py).  SODA_HIP_WINDOWS=0/1
+    # overrides for A/B runs
+    if windows is None:
+      windows = os.environ.get('SODA_HIP_WINDOWS', '1') != '0'
+    self.windows = windows
     self.stamps = stamps
     # fused 3-D kernels whose block covers the whole row, x-halos handed over
     # through LDS (MarchConfig.xshare).  Needs the row length the program will
@@ -148,7 +163,7 @@ class LowerOptions:
                        self.occupancy, self.buffer_ops, self.pipe,
                        self.pipe_rows, self.reg_budget, self.counted_waits,
                        self.stamps, self.peel, self.align_lanes, self.xshare,
-                       self.row_cells)
+                       self.row_cells, self.windows, self.inline)
     if out.prefetch is None and dim == 3:
       out.prefetch = 1
     # 2-D: resolved per fusion depth in lower() (default_prefetch)
@@ -201,6 +216,14 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
       stencil.dim, iterated=stencil.iterate > 1)
   _check_native(stencil)
   stencil.check_preserve()
+  # the module's program from here on is a DERIVED one: same tensors the
+  # caller sees (inputs, outputs, their windows and boxes), other locals
+  if opts.inline and opts.strategy != 'lds':
+    from soda_amd.optimization import pointwise
+    stencil = pointwise.inline_pointwise(stencil)
+  if opts.windows and opts.strategy != 'lds':
+    from soda_amd.optimization import windows
+    stencil = windows.decompose(stencil)
   mod = Module(stencil)
   if opts.strategy == 'lds':
     if stencil.preserve_border:
@@ -340,7 +363,17 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
             # not fit at all the scheduler uses the others
             del mod.kernels[keep[0]:], mod.passes[keep[1]:], \
                 mod.chunks[keep[2]:]
-      add_march_pass(mod, config(1, vec, pf1, rows1))
+      # (the one-iteration kernel shares x-halos only on request: measured)
+      done1 = False
+      if share and opts.xshare:
+        keep = (len(mod.kernels), len(mod.passes), len(mod.chunks))
+        try:
+          add_march_pass(mod, config(1, vec, pf1, rows1, xshare=share))
+          done1 = True
+        except util.SemanticError:
+          del mod.kernels[keep[0]:], mod.passes[keep[1]:], mod.chunks[keep[2]:]
+      if not done1:
+        add_march_pass(mod, config(1, vec, pf1, rows1))
   if not use_march:
     add_direct_pass(mod, opts.vec or 1)
   return mod

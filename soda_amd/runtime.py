@@ -702,6 +702,80 @@ def select_peel(stencil: core.Stencil, opts: 'lower.LowerOptions',
   return chosen
 
 
+def select_shape(stencil: core.Stencil, opts: 'lower.LowerOptions',
+                 extent: Optional[Sequence[int]] = None):
+  """(cells per lane, prefetch depth) for programs whose register windows the
+  shape ladder in lower() OVER-estimates, or None to leave its choice alone.
+  The ladder counts a register per cell held; 16-bit cells are packed two to a
+  register, so for tall windows of narrow integers (erosion and xcorr hold 19
+  rows of int16 plus their partial-window tensors) it retreats to 2 cells per
+  lane -- 8-byte loads, 129 us on 8192^2 -- where 8 cells per lane COMPILE to
+  243-247 registers without spilling and run in 60-67 us
+  (profiles/r03_windows_sweep.jsonl).  So, like select_peel, ask the compiler:
+  the widest shape above the ladder's choice whose compiled one-iteration
+  kernel needs at most 256 registers and no scratch.  Trials are JIT-compiled
+  (no GPU) and remembered in the kernel cache."""
+  import copy
+  import json
+  if opts.strategy not in ('auto', 'march') or stencil.iterate > 1:
+    return None
+  # (the over-estimate comes from packed narrow cells only: a program of
+  # 32-bit cells is left to the ladder -- and spared the trial compilations,
+  # minutes for a 197-tap program like contrast)
+  if min(t.size_in_bytes for t in stencil.symbol_table.values()) >= 4:
+    return None
+  base = copy.copy(opts)
+  base.peel = 0
+  mod0 = lower.lower(stencil, base)
+  one = [k for k in mod0.kernels if k.tune and k.tune.get('fused') == 1 and
+         'axis' in k.tune]
+  if not one:
+    return None
+  chosen = int(one[0].tune.get('vec') or 1)
+  want = int(opts.vec or lower.default_vec(stencil))
+  if chosen >= want:
+    return None
+  key = hashlib.sha256(('shape1\0' + compiler_version() + '\0' +
+                        '\0'.join(COMPILE_OPTIONS) + '\0%d\0' % want +
+                        mod0.source).encode()).hexdigest()[:24]
+  memo = os.path.join(CACHE_DIR, 'shape_%s.json' % key)
+  try:
+    with open(memo) as f:
+      got = json.load(f)
+    return tuple(got) if got else None
+  except (OSError, ValueError):
+    pass
+  found = None
+  vec = want
+  while vec > chosen and found is None:
+    for pf in (2, 1):
+      trial = copy.copy(base)
+      trial.vec, trial.prefetch, trial.reg_budget = vec, pf, 1 << 20
+      try:
+        mod = lower.lower(stencil, trial)
+        res = kernel_resources(compile_source(mod.source,
+                                              '%s.hip' % stencil.app_name))
+      except util.SodaError:
+        continue
+      ks = [k for k in mod.kernels if k.tune and k.tune.get('fused') == 1]
+      if not ks or int(ks[0].tune.get('vec') or 0) != vec:
+        continue
+      r = res.get(ks[0].name)
+      if r and r['scratch'] == 0 and 0 < r['vgpr'] <= 256:
+        found = (vec, pf)
+        break
+    vec //= 2
+  try:
+    os.makedirs(CACHE_DIR, exist_ok=True)
+    tmp = '%s.%d.tmp' % (memo, os.getpid())
+    with open(tmp, 'w') as f:
+      json.dump(list(found) if found else [], f)
+    os.replace(tmp, memo)
+  except OSError:
+    pass
+  return found
+
+
 def resolve_options(stencil: core.Stencil,
                     opts: Optional['lower.LowerOptions'],
                     extent: Optional[Sequence[int]],
@@ -718,6 +792,17 @@ def resolve_options(stencil: core.Stencil,
     out.vec = pick_vec(stencil, extent)
   if out.row_cells is None and extent is not None:
     out.row_cells = int(extent[0])   # lets blocks cover whole rows (xshare)
+  probing = probe and not os.environ.get('SODA_HIP_NO_PROBE')
+  if probing and out.prefetch is None and out.reg_budget is None and \
+      out.strategy in ('auto', 'march') and \
+      lower.march_supported(stencil) is None:
+    try:
+      shape = select_shape(stencil, out, extent)
+    except (util.SodaError, OSError):
+      shape = None
+    if shape:
+      out.vec, out.prefetch = shape
+      out.reg_budget = 1 << 20
   if out.peel is None and out.strategy in ('auto', 'march') and \
       lower.march_supported(stencil) is None:
     if not probe or os.environ.get('SODA_HIP_NO_PROBE'):

@@ -80,7 +80,10 @@ def test_corpus_lowers_and_jit_compiles(built, name, tmp_path):
   # at one cell per lane)
   if stencil.dim == 2:
     assert all(p.kind == 'march2d' for p in mod.passes)
-    if name != 'contrast.soda':    # (three fused iterations of it do not fit)
+    # (three fused iterations of contrast do not fit; nor of erosion and xcorr with the
+    # partial-window tensors optimization/windows.py gives them -- the library
+    # then runs such a program one iteration per launch)
+    if name not in ('contrast.soda', 'erosion.soda', 'xcorr.soda'):
       assert sorted(p.fused_iters for p in mod.passes) == sorted({1} | set(fuse))
   else:
     assert all(p.kind == 'march3d' for p in mod.passes)

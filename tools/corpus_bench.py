@@ -22,6 +22,13 @@ def main():
   ap.add_argument('--extent3', type=int, nargs=3, default=[512, 512, 512])
   ap.add_argument('--reps', type=int, default=5)
   ap.add_argument('--only', nargs='*', default=[])
+  ap.add_argument('--vec', type=int, default=None)
+  ap.add_argument('--prefetch', type=int, default=None)
+  ap.add_argument('--no-windows', action='store_true')
+  ap.add_argument('--no-inline', action='store_true')
+  ap.add_argument('--tile-rows', type=int, default=None)
+  ap.add_argument('--reg-budget', type=int, default=None)
+  ap.add_argument('--out', default=None)
   args = ap.parse_args()
   dev = torch.device('cuda', 0)
   s = torch.cuda.current_stream().cuda_stream
@@ -33,8 +40,14 @@ def main():
     extent = args.extent2 if st.dim == 2 else args.extent3
     shape = tuple(extent[::-1])
     try:
-      prog = runtime.Program(st, lower.LowerOptions(strategy=args.strategy),
-                             extent=extent)
+      prog = runtime.Program(
+          st, lower.LowerOptions(strategy=args.strategy, vec=args.vec,
+                                 prefetch=args.prefetch,
+                                 reg_budget=args.reg_budget,
+                                 windows=False if args.no_windows else None,
+                                 inline=False if args.no_inline else None,
+                                 tile_rows=args.tile_rows),
+          extent=extent)
     except Exception as e:   # noqa
       print(json.dumps(dict(program=name, error=str(e)[:200])), flush=True)
       continue
@@ -61,15 +74,22 @@ def main():
     bytes_cell = sum(t.size_in_bytes for t in st.input_types) + sum(
         t.size_in_bytes for t in st.output_types)
     launches = prog.last_launches()[0]
-    print(json.dumps(dict(
+    row = dict(
         program=name, extent=extent, iterate=st.iterate,
+        kernels=[k.name for k in prog.module.kernels],
+        vgprs=[prog.resources.get(k.name, {}).get('vgpr')
+               for k in prog.module.kernels],
         stages=len(st.local_stmts) + len(st.output_stmts),
         families=sorted({p.kind for p in prog.module.passes}),
         launches=launches, ms_per_run=round(ms, 4),
         us_per_iteration=round(ms * 1e3 / st.iterate, 1),
         algorithmic_bytes_per_cell_iter=bytes_cell,
         algorithmic_GBs=round(cells * bytes_cell * st.iterate / ms / 1e6, 1),
-        cells_iters_per_s=cells * st.iterate / ms * 1e3)), flush=True)
+        cells_iters_per_s=cells * st.iterate / ms * 1e3)
+    print(json.dumps(row), flush=True)
+    if args.out:
+      with open(args.out, 'a') as f:
+        f.write(json.dumps(row) + '\n')
     prog.close()
     del ins, outs
 
