@@ -72,7 +72,7 @@ class LowerOptions:
                nt_load: Optional[bool] = None, xcd_swizzle: bool = True,
                edge_loads: bool = True, tile_rows: Optional[int] = None,
                warm_guards: bool = False, interleave: bool = False,
-               lane_shift: str = 'dpp', min_waves: int = 0,
+               lane_shift: Optional[str] = None, min_waves: int = 0,
                occupancy: int = 0, buffer_ops: bool = True,
                pipe: Optional[int] = None, pipe_rows: int = 2,
                reg_budget: Optional[int] = None,
@@ -200,13 +200,34 @@ def default_pipe(fused_iters: int) -> int:
   return 1
 
 
-def default_prefetch(fused_iters: int) -> int:
+def default_lane_shift(fused_iters: int, dim: int) -> str:
+  """How a lane gets its neighbours' cells.  One iteration to a few per launch:
+  DPP whole-wave shifts, folded into the consuming add.  Deep 2-D fusion
+  (T >= 8): 'mixh' -- the two directions on two different pipes, down through
+  DPP (vector ALU), up through ds_swizzle (the LDS crossbar), on 32-lane half
+  strips.  A DPP-carrying instruction costs the issuing SIMD ~4-8 cycles, a
+  swizzle occupies the CU's shared LDS pipe; all of either kind is the same
+  speed (T=12: 148.3 / 148.5 us), half of each is faster although a half strip
+  has fewer valid lanes, and needs 11 registers less, which buys two more rows
+  in flight (profiles/r03_sweep_mixh_*.json, jacobi2d, us per launch, dpp ->
+  mixh: T=12 on 8192^2 146.3 -> 136.2, on the 4296- / 1224-row slabs of a 2- /
+  8-GPU run 89.4 -> 79.7 / 39.1 -> 34.8; T=8 114.3 -> 114.0, 31.9 -> 29.7;
+  T=4 100.4 -> 101.1, 19.5 -> 20.0: DPP stays)."""
+  return 'mixh' if dim == 2 and fused_iters >= 8 else 'dpp'
+
+
+def default_prefetch(fused_iters: int, lane_shift: str = 'dpp') -> int:
   """Rows a 2-D marching wave keeps in flight ahead of the one it computes.
   With the loop body branch-free (buffer addressing) the depth is real:
   jacobi2d 8192^2, one iteration per launch, 99.9 / 94.0 / 92.6 / 90.9 us at
   depth 1 / 2 / 4 / 8; the fused kernels have less to hide and fewer registers
-  to spare (T=8: 116 us at 4 vs 119 at 2; T=12: 149 at 2 vs 153 at 4)."""
-  return 8 if fused_iters <= 2 else 4 if fused_iters <= 8 else 2
+  to spare (T=8: 116 us at 4 vs 119 at 2; T=12 with DPP shifts: 149 at 2 vs
+  153 at 4; with 'mixh' shifts, 11 registers leaner: 149.6 at 2, 136.2 at 4)."""
+  if fused_iters <= 2:
+    return 8
+  if fused_iters <= 8 or lane_shift == 'mixh':
+    return 4
+  return 2
 
 
 def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
@@ -273,14 +294,25 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
 
     out_bytes = min(t.size_in_bytes for t in stencil.output_types)
 
-    def config(t: int, vec: int, pf: int, rows: Optional[int] = None,
-               xshare: int = 0) -> MarchConfig:
+    def shift_for(t: int, xshare: int = 0) -> str:
+      if opts.lane_shift is not None:
+        return opts.lane_shift
+      if xshare or pipe_for(t) > 1 or opts.waves_x * opts.waves_y != 1 or \
+          not opts.buffer_ops:
+        return 'dpp'
+      return default_lane_shift(t, stencil.dim)
+
+    def config(t: int, vec: int, pf: Optional[int],
+               rows: Optional[int] = None, xshare: int = 0) -> MarchConfig:
+      shift = shift_for(t, xshare)
+      if pf is None:
+        pf = default_prefetch(t, shift)
       cfg = MarchConfig(t, vec, opts.chunk_rows or 64, pf,
                         opts.waves_x, opts.waves_y, opts.nt_store,
                         opts.nt_load, opts.xcd_swizzle, opts.edge_loads,
                         rows or opts.tile_rows, opts.warm_guards,
                         opts.interleave,
-                        opts.lane_shift, opts.min_waves, opts.occupancy,
+                        shift, opts.min_waves, opts.occupancy,
                         opts.buffer_ops,
                         pipe_for(t), opts.pipe_rows, opts.counted_waits,
                         opts.stamps, peel_for(t),
@@ -354,8 +386,7 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
         keep = (len(mod.kernels), len(mod.passes), len(mod.chunks))
         for xs in ([share, 0] if share and t > 1 else [0]):
           try:
-            add_march_pass(mod, config(t, vec,
-                                       opts.prefetch or default_prefetch(t),
+            add_march_pass(mod, config(t, vec, opts.prefetch or None,
                                        xshare=xs))
             break
           except util.SemanticError:

@@ -195,6 +195,7 @@ class MarchConfig:
                     '_bp' if self.lane_shift == 'bperm' else
                     '_swz' if self.lane_shift == 'swz' else
                     '_swzh' if self.lane_shift == 'swzh' else
+                    '_mixh' if self.lane_shift == 'mixh' else
                     '_ldsx' if self.lane_shift == 'lds' else
                     '_noshift' if self.lane_shift == 'none' else '') + (
                         '_mw%d' % self.min_waves if self.min_waves else '') + (
@@ -387,7 +388,7 @@ class _MarchKernel:
     # its rows start on a 64*V-cell boundary)
     self.edge = (0, 0)
     # lanes that form one strip: the whole wave, or each 32-lane half
-    self.group = 32 if self.cfg.lane_shift == 'swzh' else 64
+    self.group = 32 if self.cfg.lane_shift in ('swzh', 'mixh') else 64
     if self.cfg.edge_loads and self.cfg.lane_shift in ('dpp', 'none', 'lds'):
       # (the edge cells enter through DPP's `old` operand)
       lo = hi = 0
@@ -820,6 +821,10 @@ class _MarchKernel:
                  % (o, e, e, max(0, -wlo[0]), e, max(0, whi[0])))
     self.use_bperm = self.cfg.lane_shift == 'bperm'
     self.use_swz = self.cfg.lane_shift in ('swz', 'swzh')
+    # 'mixh': the two shift directions on two different pipes -- down through
+    # DPP (vector ALU), up through ds_swizzle (the LDS crossbar, shared by the
+    # four SIMDs of a CU) -- on half strips, as 'swzh'
+    self.use_mix = self.cfg.lane_shift == 'mixh'
     if self.use_bperm:
       self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
       self.w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
@@ -1218,7 +1223,7 @@ class _MarchKernel:
           for _ in range(abs(lane_off)):
             expr = 'soda_lane_from(%s, %s)' % (
                 'lane_dn_addr' if lane_off < 0 else 'lane_up_addr', expr)
-        elif self.use_swz:
+        elif self.use_swz or (self.use_mix and lane_off > 0):
           expr = src
           for _ in range(abs(lane_off)):
             expr = 'soda_lane_%s%d(%s)' % ('dn' if lane_off < 0 else 'up',
@@ -1231,7 +1236,8 @@ class _MarchKernel:
         line = '      const %s %s = %s;' % (p.ctype, tmp, expr)
         # a shift of a row produced in an EARLIER tick can be issued ahead
         # of the previous stage's arithmetic (latency hidden behind it)
-        early = (self.use_bperm or self.use_swz) and (
+        early = (self.use_bperm or self.use_swz or
+                 (self.use_mix and lane_off > 0)) and (
             p.is_input or age > 0) and not (p.is_input and self.n_edge) \
             and not p.xs
         (_early if early else _pre).append(line)
@@ -1431,6 +1437,7 @@ class _MarchKernel:
                              waves_per_block=self.waves, warm=self.warm,
                              fixed=self.cfg.chunk_fixed, occupancy=self.cfg.occupancy,
                              pipe=self.W, vec=self.V, step_ops=step_ops,
+                             lane_shift=self.cfg.lane_shift,
                              warm_saved=saved,
                              lane_redundancy=64.0 / self.strip_lanes,
                              peel_trips=self.peeled // self.U,

@@ -319,18 +319,19 @@ namespace {
 
 const int kSimds = 1024;
 // Constants of the launch-time model, fitted (tools/fit_model.py, least squares
-// on the log ratio) to 64 measured pass times -- jacobi2d T = 1..12 on eight
-// extents from 8192 x 600 to 8192^2, heat3d T = 1, 2 on four
-// (profiles/r03_model_data.jsonl): rms error 9 % (17 % with round 2's hand
-// fits), and the schedules the model picks for 100 iterations cost at most 3 %
-// more than the ones picked by the clock on every one of those extents (the
-// hand fits: +19-20 % on the 1120- and 1224-row slabs of an 8-GPU run).
+// on the log ratio) to 128 measured pass times -- jacobi2d T = 1..12 on eight
+// extents from 8192 x 600 to 8192^2, with DPP and with mixed DPP / swizzle
+// lane shifts, heat3d T = 1, 2 on four (profiles/r03_model_data.jsonl,
+// r03_model_data2.jsonl): rms error 9 % (15-17 % with round 2's hand fits), and
+// the schedules the model picks for 100 iterations cost at most 6 % more than
+// the ones picked by the clock on every one of those extents (the hand fits:
+// +19-20 % on the 1120- and 1224-row slabs of an 8-GPU run).
 // tests/test_hip_parity.py::test_model_schedule_is_close_to_the_calibrated_one
 // re-checks that on the GPU.
-const double kHbmBytesPerNs = 6551.0;
-const double kLaunchNs = 2306.0;
-const double kWaveNs = 522.0;          // per wave per SIMD of the grid
-const double kNormP = 2.294;           // time = (issue^p + memory^p)^(1/p)
+const double kHbmBytesPerNs = 6369.0;
+const double kLaunchNs = 2547.0;
+const double kWaveNs = 391.0;          // per wave per SIMD of the grid
+const double kNormP = 2.708;           // time = (issue^p + memory^p)^(1/p)
 const int64_t kBufWindowMax = 1ll << 30;      // SODA_BUF_WINDOW_MAX, soda_rt.h
 
 int waves_per_simd(int vgprs) {
@@ -345,7 +346,7 @@ int waves_per_simd(int vgprs) {
 double issue_share(int64_t k) { return k == 1 ? 2.0 : k == 2 ? 1.2 : 1.0; }
 // the same for the time model, fitted together with the constants above
 double time_share(int64_t k) {
-  return k == 1 ? 1.284 : k == 2 ? 1.585 : k == 3 ? 1.377 : 1.01;
+  return k == 1 ? 1.312 : k == 2 ? 1.475 : k == 3 ? 1.365 : 1.046;
 }
 
 // Length (cells along the marched dimension) one wave should own.  The waves

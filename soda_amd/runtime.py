@@ -401,7 +401,9 @@ def compile_source(source: str, name: str = 'soda.hip',
 # "Constants of the launch-time model", tools/fit_model.py); the fused kernels
 # sustain 3.2-3.8 cycles per wave64 instruction at ~2.3 GHz with their lane
 # shifts (profiles/)
-NS_PER_VALU_OP = 1.187
+NS_PER_VALU_OP = 1.28
+# ... of a kernel whose lane shifts are split between DPP and ds_swizzle
+MIXH_FACTOR = 0.849
 
 
 def make_plan(mod: lower.Module,
@@ -454,7 +456,8 @@ def make_plan(mod: lower.Module,
       d.pipe = int(tune.get('pipe') or 1)
       d.chunk_fixed = 1 if tune.get('fixed') else 0
       d.vgprs = int((resources or {}).get(k.name, {}).get('vgpr') or 0)
-      d.step_ns = float(tune.get('step_ops') or 0.0) * NS_PER_VALU_OP
+      d.step_ns = float(tune.get('step_ops') or 0.0) * NS_PER_VALU_OP * (
+          MIXH_FACTOR if tune.get('lane_shift') == 'mixh' else 1.0)
       d.warm_saved = float(tune.get('warm_saved') or 0.0)
       d.bytes_per_cell = io_bytes
       d.lane_redundancy = float(tune.get('lane_redundancy') or 1.0)

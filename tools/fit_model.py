@@ -45,7 +45,8 @@ def points(path):
         cells *= e
       out.append(dict(ext=ext, T=int(t), waves=waves, cap=waves_per_simd(p['vgpr']),
                       steps=max(1.0, per_wave + d['warm'] - d['warm_saved']),
-                      step_ops=d['step_ns'] / NS_PER_OP_IN_DATA, per_wave=per_wave,
+                      step_ops=d['step_ns'] / d.get('ns_per_op', NS_PER_OP_IN_DATA),
+                      mix=d.get('shift') == 'mixh', per_wave=per_wave,
                       warm=d['warm'], lanes=max(1.0, d['lanes']), cells=cells,
                       bpc=d['bytes_per_cell'], pipe=max(1, d['pipe']),
                       measured=p['measured_us'] * 1e3, old=p['model_us'] * 1e3,
@@ -54,7 +55,7 @@ def points(path):
 
 
 def model(pt, th):
-  ns_op, s1, s2, s3, s4, rate, p, launch, wave_ns = th
+  ns_op, s1, s2, s3, s4, rate, p, launch, wave_ns, mix = th
   share_of = {1: s1, 2: s2, 3: s3}
   def sh(k):
     return share_of.get(k, s4)
@@ -65,6 +66,8 @@ def model(pt, th):
     rk = max(1, -(-rem // SIMDS))
     share += rk * sh(rk)
   valu = share * pt['steps'] * pt['step_ops'] * ns_op / pt['pipe']
+  if pt.get('mix'):
+    valu *= mix     # runtime.MIXH_FACTOR
   rows_factor = (pt['per_wave'] + pt['warm']) / pt['per_wave']
   bytes_ = pt['cells'] * pt['bpc'] * (0.5 * pt['lanes'] * rows_factor + 0.5)
   mem = bytes_ / rate
@@ -73,11 +76,14 @@ def model(pt, th):
 
 
 def main():
-  pts = points(sys.argv[1] if len(sys.argv) > 1 else 'profiles/r03_model_data.jsonl')
+  pts = []
+  for path in (sys.argv[1].split(',') if len(sys.argv) > 1 else
+               ['profiles/r03_model_data.jsonl']):
+    pts.extend(points(path))
   pts2 = pts     # 2-D and 3-D together
-  x0 = np.array([1.4, 2.0, 1.2, 1.0, 1.0, 6300.0, 3.0, 2000.0, 0.0])
-  lo = np.array([0.5, 1.0, 0.8, 0.8, 0.8, 4000.0, 1.0, 0.0, 0.0])
-  hi = np.array([3.0, 4.0, 2.5, 2.5, 2.5, 8000.0, 8.0, 10000.0, 3000.0])
+  x0 = np.array([1.4, 2.0, 1.2, 1.0, 1.0, 6300.0, 3.0, 2000.0, 0.0, 0.8])
+  lo = np.array([0.5, 1.0, 0.8, 0.8, 0.8, 4000.0, 1.0, 0.0, 0.0, 0.4])
+  hi = np.array([3.0, 4.0, 2.5, 2.5, 2.5, 8000.0, 8.0, 10000.0, 3000.0, 1.2])
 
   def resid(th):
     return [math.log(model(q, th) / q['measured']) for q in pts2]
@@ -85,7 +91,7 @@ def main():
   fit = least_squares(resid, x0, bounds=(lo, hi))
   th = fit.x
   names = ['ns_per_op', 'share1', 'share2', 'share3', 'share4+', 'bytes_per_ns',
-           'p', 'launch_ns', 'ns_per_wave_per_simd']
+           'p', 'launch_ns', 'ns_per_wave_per_simd', 'mixh_factor']
   print({n: round(float(v), 3) for n, v in zip(names, th)})
   r = np.array(resid(th))
   old = np.array([math.log(q['old'] / q['measured']) for q in pts2])
@@ -139,10 +145,12 @@ def schedules(path, th, passes=(12, 8, 4, 1), iterate=100):
 
 
 if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'sched':
-  pts_ = points(sys.argv[1])
-  x0 = np.array([1.4, 2.0, 1.2, 1.0, 1.0, 6300.0, 3.0, 2000.0, 0.0])
-  lo = np.array([0.5, 1.0, 0.8, 0.8, 0.8, 4000.0, 1.0, 0.0, 0.0])
-  hi = np.array([3.0, 4.0, 2.5, 2.5, 2.5, 8000.0, 8.0, 10000.0, 3000.0])
+  pts_ = []
+  for path in sys.argv[1].split(','):
+    pts_.extend(points(path))
+  x0 = np.array([1.4, 2.0, 1.2, 1.0, 1.0, 6300.0, 3.0, 2000.0, 0.0, 0.8])
+  lo = np.array([0.5, 1.0, 0.8, 0.8, 0.8, 4000.0, 1.0, 0.0, 0.0, 0.4])
+  hi = np.array([3.0, 4.0, 2.5, 2.5, 2.5, 8000.0, 8.0, 10000.0, 3000.0, 1.2])
   fit = least_squares(lambda th: [math.log(model(q, th) / q['measured'])
                                   for q in pts_], x0, bounds=(lo, hi))
-  schedules(sys.argv[1], fit.x)
+  schedules(sys.argv[1].split(',')[-1], fit.x)

@@ -83,7 +83,10 @@ def main():
                                           bytes_per_cell=d.bytes_per_cell,
                                           block=list(d.block), vec=d.vec,
                                           waves_along=d.waves_along, pipe=d.pipe,
-                                          strip_cells=kk.tile[0]))
+                                          strip_cells=kk.tile[0],
+                                          shift=(kk.tune or {}).get('lane_shift'),
+                                          ns_per_op=runtime.NS_PER_VALU_OP,
+                                          step_ops=(kk.tune or {}).get('step_ops')))
     print(json.dumps(row), flush=True)
     if args.out:
       with open(args.out, 'a') as f:
