@@ -671,6 +671,7 @@ def main():
           'value': cells * args.iterate / (ms * 1e-3),
           'unit': 'cells*iters/s', 'ms_per_step': ms,
           'kernel': prog1.module.kernels[0].name,
+          'kernel_key': runtime.source_key(prog1.module.source),
           'roofline': {'bound': 'hbm', 'achieved': k1, 'peak': HBM_PEAK_GBS,
                        'unit': 'GB/s', 'frac': k1 / HBM_PEAK_GBS,
                        'frac_of_measured_copy':

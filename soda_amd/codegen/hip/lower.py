@@ -237,6 +237,13 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
       stencil.dim, iterated=stencil.iterate > 1)
   _check_native(stencil)
   stencil.check_preserve()
+  # arithmetic per cell of one iteration AS WRITTEN (the rewrites below fold
+  # and split statements; what the shape ladder wants to know is how much the
+  # program computes)
+  from soda_amd import ir as _ir
+  work = sum(_ir.op_count(s.stmt.expr) +
+             sum(_ir.op_count(l.expr) for l in s.stmt.let)
+             for s in stencil.ordered_stages)
   # the module's program from here on is a DERIVED one: same tensors the
   # caller sees (inputs, outputs, their windows and boxes), other locals
   if opts.inline and opts.strategy != 'lds':
@@ -333,10 +340,6 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     # hundreds of instructions per cell has nothing to hide behind a deep
     # prefetch queue and pays for its registers in resident waves (contrast,
     # 393 operations per cell: 703 us at 8 rows in flight, 660 at 2)
-    from soda_amd import ir
-    work = sum(ir.op_count(s.stmt.expr) +
-               sum(ir.op_count(l.expr) for l in s.stmt.let)
-               for s in stencil.ordered_stages)
     first = default_prefetch(1) if stencil.dim == 2 and work < 128 else \
         (2 if stencil.dim == 2 else 1)
     pfs = [opts.prefetch] if opts.prefetch else [first, 2, 1]

@@ -69,6 +69,19 @@ def main():
       entry['gui_active_cycles_per_xcd'] = (
           sum(v['GRBM_GUI_ACTIVE']) / len(v['GRBM_GUI_ACTIVE']) / 8)
     result[name] = entry
+  # tie every measurement to the build of the kernel it was taken on: bench.py
+  # reports the content key of the module it JIT-built (roofline.kernel_key)
+  # and drops a traffic figure whose key differs from its own
+  if len(sys.argv) > 6:
+    with open(sys.argv[6]) as f:
+      line = [l for l in f.read().splitlines() if l.startswith('{')][-1]
+    bench = json.loads(line)
+    pairs = [(bench['roofline'].get('kernel'), bench['roofline'].get('kernel_key'))]
+    si = bench.get('single_iter') or {}
+    pairs.append((si.get('kernel'), si.get('kernel_key')))
+    for name, key in pairs:
+      if name in result and key:
+        result[name]['kernel_key'] = key
   with open(out_json, 'w') as f:
     json.dump(result, f, indent=1, sort_keys=True)
   print(json.dumps(result, indent=1, sort_keys=True))
