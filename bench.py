@@ -331,6 +331,13 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
     raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+  # Rehearsal on a box with ONE GPU (tests/test_dist.py): SODA_BENCH_ONE_GPU=1
+  # maps every rank to device 0 and SODA_BENCH_BACKEND=gloo carries the halos
+  # (RCCL refuses two ranks on one device); the code path is otherwise the
+  # N-GPU one.  Never set by the driver.
+  backend = os.environ.get('SODA_BENCH_BACKEND', 'nccl')
+  if os.environ.get('SODA_BENCH_ONE_GPU'):
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   tdist = None
@@ -341,6 +348,8 @@ def main():
       os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
       os.environ.setdefault('MASTER_PORT', '29531')
       tdist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    elif backend != 'nccl':
+      tdist.init_process_group(backend)
     else:
       tdist.init_process_group('nccl', device_id=dev)
     rccl_world = tdist.get_world_size()
@@ -541,31 +550,48 @@ def main():
   if world > 1 and args.overlap == 'auto':
     # both ways, a few steps each; every rank must take the same decision
     trial = {}
+    failed = None
     for way in (True, False, True, False):
+      if way and failed:
+        continue
       mode['overlap'] = way
-      one_step()
-      torch.cuda.synchronize()
-      tdist.barrier()
-      t0 = time.perf_counter()
-      for _ in range(3):
+      dt = 0.0
+      try:
         one_step()
-      torch.cuda.synchronize()
-      t = torch.tensor([time.perf_counter() - t0], device=dev,
+        torch.cuda.synchronize()
+        tdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+          one_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+      except Exception as e:       # the overlapped way is new on real links:
+        if not way:                # it must not take the serial one down
+          raise
+        failed = '%s: %s' % (type(e).__name__, str(e)[:200])
+      # every rank learns whether ANY rank failed (and the slowest time)
+      t = torch.tensor([dt, 1.0 if (way and failed) else 0.0], device=dev,
                        dtype=torch.float64)
       tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-      trial[way] = min(trial.get(way, 1e9), float(t.item()) / 3 * 1e3)
+      if way and float(t[1].item()) > 0:
+        failed = failed or 'another rank failed'
+        trial[True] = float('inf')
+        continue
+      trial[way] = min(trial.get(way, 1e9), float(t[0].item()) / 3 * 1e3)
     mode['overlap'] = trial[True] <= trial[False]
-    overlap_trial = {'overlapped_ms_per_step': trial[True],
-                     'serial_ms_per_step': trial[False]}
+    overlap_trial = {'overlapped_ms_per_step': trial[True]
+                     if trial[True] != float('inf') else None,
+                     'serial_ms_per_step': trial[False],
+                     **({'overlapped_failed': failed} if failed else {})}
   for _ in range(args.warmup):
     one_step()
   torch.cuda.synchronize()
   # launches of one step: count them once, outside the timed region
   _orig_step = step_fn
 
-  def counting_step(dst, src, lext, iters):
+  def counting_step(dst, src, lext, iters, **kw):
     nonlocal launches_per_step
-    _orig_step(dst, src, lext, iters)
+    _orig_step(dst, src, lext, iters, **kw)
     launches_per_step += prog.last_launches()[0]
 
   step_fn_real, step_fn = step_fn, counting_step
@@ -585,6 +611,8 @@ def main():
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
     elapsed = float(t.item())
+  transport = ('RCCL send/recv' if backend == 'nccl' else backend +
+               ' (REHEARSAL on one GPU, not a measurement)')
 
   # the dominant kernel again, now at the clocks the timed steps ran at (the
   # pre-measurement above starts ~1 ms after idle and reads up to 20 % slow on
@@ -637,7 +665,7 @@ def main():
                                 if world > 1 else 0,
           'overlap': bool(mode['overlap']),
           **({'overlap_trial': overlap_trial} if overlap_trial else {}),
-          'transport': 'RCCL send/recv (torch.distributed, one rank per GPU)'
+          'transport': transport + ' (torch.distributed, one rank per GPU)'
                        if world > 1 else 'none',
           'ghost_rows_per_side': (slab.ghost_hi or slab.ghost_lo)
                                  if geo_world > 1 else 0,

@@ -404,6 +404,44 @@ def test_bench_launcher_refuses_without_enough_gpus():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('overlap', ['auto', 'on', 'off'])
+def test_bench_two_ranks_rehearsed_on_one_gpu(overlap):
+  """bench.py's N-GPU path end to end under torchrun -- slabs, chained steps,
+  the overlapped exchange on a side stream (dist.StreamOverlap through the real
+  torch.distributed API), the overlap trial, the JSON line -- with both ranks
+  on the ONE GPU of the box and gloo carrying the halos (RCCL refuses two ranks
+  on a device).  A functional rehearsal, not a measurement."""
+  import json
+  import subprocess
+  import sys
+  env = dict(os.environ)
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    env.pop(k, None)
+  env.update(SODA_BENCH_ONE_GPU='1', SODA_BENCH_BACKEND='gloo')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'),
+         '--gpus', '2', '--steps', '3', '--warmup', '1', '--extent', '2048',
+         '2048', '--iterate', '48', '--fuse', '12', '4', '--exchange-every',
+         '24', '--overlap', overlap, '--no-cpu-baseline', '--no-single-iter']
+  run = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=600)
+  assert run.returncode == 0, run.stderr[-3000:]
+  line = [l for l in run.stdout.splitlines() if l.startswith('{')][-1]
+  out = json.loads(line)
+  assert out['n_gpus'] == 2 and out['value'] > 0
+  cfg = out['config']
+  assert cfg['exchanges_per_step'] == 2 and cfg['ghost_rows_per_side'] == 24
+  assert 'REHEARSAL' in cfg['transport']
+  if overlap == 'auto':
+    trial = cfg['overlap_trial']
+    assert 'overlapped_failed' not in trial, trial
+    assert trial['overlapped_ms_per_step'] > 0 and trial['serial_ms_per_step'] > 0
+  else:
+    assert cfg['overlap'] == (overlap == 'on')
+
+
+@pytest.mark.gpu
 def test_bench_launcher_on_the_gpu_box():
   """On the GPU box: with two or more GPUs the self-launched 2-rank run must
   come back with one JSON line from rank 0 and `rccl_world` = 2 (the RCCL
