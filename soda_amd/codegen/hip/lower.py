@@ -251,7 +251,11 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     stencil = pointwise.inline_pointwise(stencil)
   if opts.windows and opts.strategy != 'lds':
     from soda_amd.optimization import windows
-    stencil = windows.decompose(stencil)
+    # (the marching kernels reduce dimension-0 windows themselves, all cells
+    # of a lane jointly; `direct` kernels get chains in every dimension)
+    marching = opts.strategy in ('auto', 'march') and \
+        march_supported(stencil) is None
+    stencil = windows.decompose(stencil, skip_dims=(0,) if marching else ())
   mod = Module(stencil)
   if opts.strategy == 'lds':
     if stencil.preserve_border:
@@ -325,7 +329,7 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
                         opts.stamps, peel_for(t),
                         opts.align_lanes if opts.align_lanes is not None else
                         (max(1, 64 // (vec * out_bytes)) if opts.nt_store
-                         else 1), xshare)
+                         else 1), xshare, bool(opts.windows))
       cfg.chunk_fixed = opts.chunk_rows is not None
       return cfg
 

@@ -95,7 +95,11 @@ class MarchConfig:
                min_waves: int = 0, occupancy: int = 0,
                buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4,
                counted_waits: bool = False, stamps: bool = False,
-               peel: int = -1, align_lanes: int = 1, xshare: int = 0):
+               peel: int = -1, align_lanes: int = 1, xshare: int = 0,
+               xwindow: bool = True):
+    # integer window reductions along dimension 0 evaluated for all cells of
+    # a lane jointly (_emit_xwindow)
+    self.xwindow = xwindow
     # x-halos shared through LDS: a block of `xshare` waves covers the WHOLE
     # row (extent[0] <= xshare * 64 * vec, checked at launch), every wave a
     # strip of 64 fully valid lanes; the one cell a fused iteration needs from
@@ -1246,7 +1250,10 @@ class _MarchKernel:
 
     body: List[str] = []
     dst_slot = self.slot_of(n, k, 0)
-    if self.cfg.interleave and not stage.stmt.let:
+    xwin = self._xwindow(stage) if n.keep is None and not guard else None
+    if xwin is not None:
+      self._emit_xwindow(n, stage, xwin, dst_slot, operand, body)
+    elif self.cfg.interleave and not stage.stmt.let:
       # all cells of the row tile at once, operation-major
       cells = [(j, e) for j in self.rows_of(n) for e in range(self.V)]
 
@@ -1272,7 +1279,9 @@ class _MarchKernel:
       for (j, e), r in zip(cells, results):
         body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
                     (n.var, dst_slot, j, e, n.ctype, r))
-    for j in ([] if (self.cfg.interleave and not stage.stmt.let) else self.rows_of(n)):
+    for j in ([] if (xwin is not None or
+                     (self.cfg.interleave and not stage.stmt.let))
+              else self.rows_of(n)):
       for e in range(self.V):
 
         def load(ref: ir.Ref, _e=e, _j=j, _stage=stage) -> str:
@@ -1356,6 +1365,97 @@ class _MarchKernel:
                 dst_slot, j))
     if n.store_slot is not None:
       self._emit_store(n, stage.name, dst_slot)
+
+  # -- integer window reductions along dimension 0, all cells of a lane jointly --
+  def _xwindow(self, stage):
+    """(op, parent, first offset relative to the cell, taps) if `stage` is an
+    association-free reduction over a contiguous run of dimension-0 taps of one
+    tensor (optimization/windows.py states when it is), else None."""
+    if not self.cfg.xwindow:
+      return None
+    from soda_amd.optimization import windows
+    table = dict(self.st.symbol_table)
+    m = windows._match(stage.stmt, table)
+    if m is None or m[2] != 0:
+      return None
+    op, parent, _, _, taps, base = m
+    off = tuple(a - b for a, b in zip(base, stage.st_idx))
+    return op, parent, off, taps
+
+  def _emit_xwindow(self, n: _Node, stage, xwin, dst_slot: int, operand,
+                    body: List[str]) -> None:
+    """A window of `taps` cells along dimension 0, for the V cells of a lane at
+    once: the V + taps - 1 cells the lane's windows cover are brought into the
+    lane ONCE (whole fragments of the lanes to the right: ~ (taps - 1) lane
+    moves instead of a move per tap per cell), then
+
+      +        out[0] = the first window, out[e + 1] = out[e] + in[e + taps]
+               - in[e]: taps - 1 + 2 (V - 1) operations for V cells, in int32
+               (exact: the values are narrower than 32 bits, windows.py);
+      min/max  the windows share the middle block in[V-1 .. taps-1]; suffix
+               reductions of in[0 .. V-2] and prefix reductions of
+               in[taps .. taps+V-2] complete them: ~ taps + 3 V operations.
+
+    Integer arithmetic in any order gives the same bits as the statement's
+    left-to-right text; the statement's cast is applied per cell as before."""
+    op, pname, off, taps = xwin
+    V = self.V
+    for j in self.rows_of(n):
+      tag = '%s_k%d_r%d' % (n.var, dst_slot, j)
+      cells = []
+      for i in range(V + taps - 1):
+        o = list(off)
+        o[0] = off[0] + i
+        cells.append(operand(pname, tuple(o), j, 0))
+      dst = ['%s_s%d_r%d[%d]' % (n.var, dst_slot, j, e) for e in range(V)]
+      body.append('      {')
+      if op == '+':
+        body.append('        int xw_%s = %s;' % (tag, ' + '.join(
+            '(int)%s' % c for c in cells[:taps])))
+        body.append('        %s = (%s)xw_%s;' % (dst[0], n.ctype, tag))
+        for e in range(1, V):
+          body.append('        xw_%s = xw_%s + (int)%s - (int)%s;' %
+                      (tag, tag, cells[e + taps - 1], cells[e - 1]))
+          body.append('        %s = (%s)xw_%s;' % (dst[e], n.ctype, tag))
+      else:
+        fn = 'SODA_MIN' if op == 'min' else 'SODA_MAX'
+        pt = self.st.symbol_table[pname].c_type
+        lo, hi = V - 1, taps - 1            # cells every window contains
+        if lo > hi:                         # (more cells per lane than taps)
+          lo, hi = hi, hi
+        mid = '(%s)%s' % (pt, cells[lo])
+        for c in cells[lo + 1:hi + 1]:
+          mid = '%s((%s)%s, %s)' % (fn, pt, c, mid)
+        body.append('        const %s xm_%s = %s;' % (pt, tag, mid))
+        # suffix reductions of the cells below the middle block ...
+        suf = {}
+        prev = None
+        for i in range(lo - 1, -1, -1):
+          name = 'xs_%s_%d' % (tag, i)
+          expr = '(%s)%s' % (pt, cells[i]) if prev is None else \
+              '%s((%s)%s, %s)' % (fn, pt, cells[i], prev)
+          body.append('        const %s %s = %s;' % (pt, name, expr))
+          suf[i] = prev = name
+        # ... and prefix reductions of the cells above it
+        pre = {}
+        prev = None
+        for i in range(hi + 1, V + taps - 1):
+          name = 'xp_%s_%d' % (tag, i)
+          expr = '(%s)%s' % (pt, cells[i]) if prev is None else \
+              '%s(%s, (%s)%s)' % (fn, prev, pt, cells[i])
+          body.append('        const %s %s = %s;' % (pt, name, expr))
+          pre[i] = prev = name
+        for e in range(V):
+          parts = ['xm_%s' % tag]
+          if e < lo:
+            parts.append(suf[e])
+          if e + taps - 1 > hi:
+            parts.append(pre[e + taps - 1])
+          expr = parts[0]
+          for q in parts[1:]:
+            expr = '%s(%s, %s)' % (fn, expr, q)
+          body.append('        %s = (%s)(%s);' % (dst[e], n.ctype, expr))
+      body.append('      }')
 
   def _emit_store(self, n: _Node, oname: str, dst_slot: int) -> None:
     """Stores the new plane of a last-iteration output (rows and lanes that
