@@ -55,6 +55,10 @@ from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_FUSE_PRESERVE,  # noqa:
 # ---------------------------------------------------------------------------
 
 DEFAULT_COUNTED_WAITS = False
+MAX_TENSORS = 16       # SODA_HIP_MAX_TENSORS (include/soda_hip.h)
+# integer sums along the streamed dimension as sliding sums in the marching
+# kernels (march.py `slide`) instead of power-of-two chains (SODA_HIP_SLIDE=0/1)
+SLIDING_SUMS = os.environ.get('SODA_HIP_SLIDE', '1') != '0'
 
 
 class LowerOptions:
@@ -255,7 +259,14 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     # of a lane jointly; `direct` kernels get chains in every dimension)
     marching = opts.strategy in ('auto', 'march') and \
         march_supported(stencil) is None
-    stencil = windows.decompose(stencil, skip_dims=(0,) if marching else ())
+    skip = ()
+    if marching:
+      skip = ((0, None),) + (((stencil.dim - 1, '+'),) if SLIDING_SUMS else ())
+    derived = windows.decompose(stencil, skip=skip)
+    # (the auxiliaries are tensors of the launch plan: a program that would
+    # exceed the argument block's slots keeps its windows as written)
+    if len(derived.symbol_table) + len(derived.param_stmts) <= MAX_TENSORS:
+      stencil = derived
   mod = Module(stencil)
   if opts.strategy == 'lds':
     if stencil.preserve_border:
@@ -329,7 +340,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
                         opts.stamps, peel_for(t),
                         opts.align_lanes if opts.align_lanes is not None else
                         (max(1, 64 // (vec * out_bytes)) if opts.nt_store
-                         else 1), xshare, bool(opts.windows))
+                         else 1), xshare, bool(opts.windows),
+                        bool(opts.windows) and SLIDING_SUMS)
       cfg.chunk_fixed = opts.chunk_rows is not None
       return cfg
 

@@ -96,10 +96,12 @@ class MarchConfig:
                buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4,
                counted_waits: bool = False, stamps: bool = False,
                peel: int = -1, align_lanes: int = 1, xshare: int = 0,
-               xwindow: bool = True):
+               xwindow: bool = True, slide: bool = True):
     # integer window reductions along dimension 0 evaluated for all cells of
-    # a lane jointly (_emit_xwindow)
+    # a lane jointly (_emit_xwindow); integer sums along the streamed
+    # dimension as sliding sums
     self.xwindow = xwindow
+    self.slide = slide
     # x-halos shared through LDS: a block of `xshare` waves covers the WHOLE
     # row (extent[0] <= xshare * 64 * vec, checked at launch), every wave a
     # strip of 64 fully valid lanes; the one cell a fused iteration needs from
@@ -829,6 +831,28 @@ class _MarchKernel:
     # DPP (vector ALU), up through ds_swizzle (the LDS crossbar, shared by the
     # four SIMDs of a CU) -- on half strips, as 'swzh'
     self.use_mix = self.cfg.lane_shift == 'mixh'
+    # Integer sums over a run of taps along the STREAMED dimension as a sliding
+    # sum: an int32 accumulator per cell that lives across row steps,
+    #     acc += newest row;  result = cast(acc);  acc -= oldest row
+    # -- 2 operations per cell whatever the window (xcorr: 19 rows), no
+    # auxiliary tensors.  State that survives row steps: the stage must run in
+    # EVERY step from its first on (it does: a stage is never dropped again
+    # once the peeled warm-up has started it) and the accumulator is set up
+    # right before that first step from the rows the window holds then.
+    # Exact: integers narrower than 32 bits (optimization/windows.py).
+    self.slide: Dict[int, Tuple[str, Tuple[int, ...], int]] = {}
+    if self.cfg.xwindow and self.cfg.slide and self.W == 1 and \
+        not self.cfg.warm_guards and not self.cfg.interleave:
+      from soda_amd.optimization import windows
+      table = dict(self.st.symbol_table)
+      for n in self.nodes:
+        if n.stage is None or n.mirror_of is not None or n.keep is not None:
+          continue
+        m = windows._match(n.stage.stmt, table)
+        if m is None or m[0] != '+' or m[2] != self.ax:
+          continue
+        off = tuple(a - b for a, b in zip(m[5], n.stage.st_idx))
+        self.slide[id(n)] = (m[1], off, m[4])
     if self.use_bperm:
       self.w('  const int lane_dn_addr = ((lane + 63) & 63) << 2;  // byte address of lane-1')
       self.w('  const int lane_up_addr = ((lane + 1) & 63) << 2;')
@@ -903,6 +927,10 @@ class _MarchKernel:
       for n in self.nodes:
         if n.owner != wv:
           continue
+        if id(n) in self.slide:
+          for j in self.rows_of(n):
+            self.w('  int xa_%s_r%d[%d];' % (n.var, j, self.V))
+            self.w('  soda_zero_frag<int, %d>(xa_%s_r%d);' % (self.V, n.var, j))
         for s in range(n.slots):
           for j in self.rows_of(n):
             self.w('  %s %s_s%d_r%d[%d];' % (n.ctype, n.var, s, j, self.V))
@@ -1016,6 +1044,17 @@ class _MarchKernel:
         self._emit_tick(wv, i % self.U, step=i)
       self.w('  }')
       self.w('  tau += %d;' % self.peeled)
+    for n in self.nodes:
+      if id(n) in self.slide and n.owner == wv and not (
+          self.peeled and self.stage_needed(n, self.peeled - 1)):
+        # the stage's first step is the loop's first: set its accumulator up
+        self.w('  {  // sliding sum of %s: the rows its window holds now' % n.var)
+        self.w('    const int t = tau;')
+        self._shifted = {}
+        self._lx_read = set()
+        self._stage_mark = len(self.L)
+        self._emit_stage(n, 0, slide_init='only')
+        self.w('  }')
     self.w('  for (; tau < tau_end; tau += %d) {' % self.U)
     for k in range(self.U):
       self._emit_tick(wv, k)
@@ -1130,7 +1169,9 @@ class _MarchKernel:
           if self.cw and n.store_slot is not None:
             self._emit_dummy_stores(wv, only=n, salt=step + 1)
           continue
-        self._emit_stage(n, k)
+        first = step is not None and (step == 0 or
+                                      not self.stage_needed(n, step - 1))
+        self._emit_stage(n, k, slide_init='first' if first else None)
         if n.xs:
           fresh_xs.append((n, self.slot_of(n, k, 0)))
     self.shift_temps = max(self.shift_temps, len(self._shifted))
@@ -1162,9 +1203,13 @@ class _MarchKernel:
                  % (n.ctype, n.var, i, n.var, i))
     return out
 
-  def _emit_stage(self, n: _Node, k: int) -> None:
+  def _emit_stage(self, n: _Node, k: int,
+                  slide_init: Optional[str] = None) -> None:
     """One tensor's new plane at tick phase k: lane-shifted operands first
-    (shared by the stages of a tick), then one statement per cell."""
+    (shared by the stages of a tick), then one statement per cell.
+    `slide_init` (sliding sums only): 'first' -- this is the stage's first
+    step, set the accumulator up in front of it; 'only' -- emit nothing but
+    that set-up (the first step is the loop's first)."""
     stage = n.stage
     pre: List[str] = []
     guard = None
@@ -1251,7 +1296,29 @@ class _MarchKernel:
     body: List[str] = []
     dst_slot = self.slot_of(n, k, 0)
     xwin = self._xwindow(stage) if n.keep is None and not guard else None
-    if xwin is not None:
+    slide = self.slide.get(id(n))
+    if slide is not None:
+      pname, off, taps = slide
+      for j in self.rows_of(n):
+        acc = 'xa_%s_r%d' % (n.var, j)
+        for e in range(self.V):
+          def tap(i, _j=j, _e=e):
+            o = list(off)
+            o[self.ax] = off[self.ax] + i
+            return '(int)%s' % operand(pname, tuple(o), _j, _e)
+          if slide_init:
+            body.append('      %s[%d] = %s;' % (acc, e, ' + '.join(
+                tap(i) for i in range(taps - 1))))
+          if slide_init != 'only':
+            body.append('      %s[%d] += %s;' % (acc, e, tap(taps - 1)))
+            body.append('      %s_s%d_r%d[%d] = (%s)%s[%d];' %
+                        (n.var, dst_slot, j, e, n.ctype, acc, e))
+            body.append('      %s[%d] -= %s;' % (acc, e, tap(0)))
+      if slide_init == 'only':
+        self.L.extend(pre)
+        self.L.extend(body)
+        return
+    elif xwin is not None:
       self._emit_xwindow(n, stage, xwin, dst_slot, operand, body)
     elif self.cfg.interleave and not stage.stmt.let:
       # all cells of the row tile at once, operation-major
@@ -1279,7 +1346,7 @@ class _MarchKernel:
       for (j, e), r in zip(cells, results):
         body.append('      %s_s%d_r%d[%d] = (%s)(%s);' %
                     (n.var, dst_slot, j, e, n.ctype, r))
-    for j in ([] if (xwin is not None or
+    for j in ([] if (xwin is not None or slide is not None or
                      (self.cfg.interleave and not stage.stmt.let))
               else self.rows_of(n)):
       for e in range(self.V):

@@ -363,7 +363,16 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
   const int32_t n = extent[axis];
   const int wpb = (d.block[0] * d.block[1] * d.block[2] + 63) / 64;
   const int along = d.waves_along > 0 ? d.waves_along : 1;
-  const double warm = d.warm - d.warm_saved;
+  // Peeled warm-up steps compute little but still LOAD their rows.  Where
+  // peeling saves (nearly) ALL of a long warm-up -- a one-iteration kernel with
+  // a tall window, whose stages all start at the end of it: xcorr, 18 of 18
+  // steps -- "warm-up costs nothing" would shorten the chunks to 8 rows, each
+  // row read 3.25 times (measured: 123 us against 59 at 64 rows, 72 at 128,
+  // profiles/r03_sweep_xcorr_slide_chunk.json).  Such a kernel is bound by its
+  // loads: its warm-up counts in full, and like the other load-bound kernels
+  // it gets many short waves.
+  const bool load_only_warm = d.warm > 12 && d.warm_saved >= 0.75 * d.warm;
+  const double warm = load_only_warm ? d.warm : d.warm - d.warm_saved;
   (void)tile; (void)dim;
   const int cap = waves_per_simd(d.vgprs);
   if (d.pipe > 1) {
@@ -428,7 +437,7 @@ int32_t tuned_chunk(const soda_hip_kernel_desc_t& d, const int32_t* tile,
   }
   // latency-bound: more, shorter waves (not for a kernel the registers allow
   // one wave per SIMD of: it has no second wave to hide anything behind)
-  if (d.warm <= 12 && best > 64 && cap > 1) best = 64;
+  if ((d.warm <= 12 || load_only_warm) && best > 64 && cap > 1) best = 64;
   int64_t chunks = (n + best - 1) / best;
   return (int32_t)((n + chunks - 1) / chunks);   // same count, equal lengths
 }

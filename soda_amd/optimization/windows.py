@@ -111,13 +111,13 @@ def _ref(name: str, idx) -> str:
   return '%s(%s)' % (name, ', '.join(str(i) for i in idx))
 
 
-def decompose(stencil: core.Stencil,
-              skip_dims: Tuple[int, ...] = ()) -> core.Stencil:
+def decompose(stencil: core.Stencil, skip=()) -> core.Stencil:
   """The derived program (a new Stencil), or `stencil` itself if no statement
-  qualifies.  Windows along a dimension in `skip_dims` are left as written (the
-  marching kernels reduce dimension-0 windows for all cells of a lane jointly,
-  march._emit_xwindow: cheaper than chains there, where every far tap is a
-  lane move)."""
+  qualifies.  `skip`: (dimension, op) pairs left as written, op None = any --
+  the marching kernels reduce dimension-0 windows for all cells of a lane
+  jointly (march._emit_xwindow: cheaper than chains there, where every far tap
+  is a lane move) and keep sums along the streamed dimension as sliding sums
+  (two operations per cell, no auxiliary tensors)."""
   table = stencil.symbol_table
   taken = set(table) | set(stencil.param_names)
   made: Dict[Tuple[str, str, int, int], str] = {}   # (op, parent, dim, size)
@@ -174,7 +174,7 @@ def decompose(stencil: core.Stencil,
 
   for stmt in stencil.local_stmts + stencil.output_stmts:
     m = _match(stmt, table)
-    if m is None or m[2] in skip_dims:
+    if m is None or (m[2], None) in skip or (m[2], m[0]) in skip:
       continue
     op, parent, d, first, n, base = m
     lines: List[str] = []

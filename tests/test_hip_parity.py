@@ -340,6 +340,33 @@ def test_four_dimensional_program(built, iterate, extent):
   assert np.array_equal(got[idx], want[idx])
 
 
+@pytest.mark.parametrize('fuse,strategy,extent', [
+    ((3,), 'auto', (600, 150)), ((), 'auto', (1000, 333)),
+    ((2,), 'auto', (260, 70)), ((), 'direct', (600, 150))])
+def test_integer_window_forms(built, fuse, strategy, extent):
+  """tests/golden/winsum2d.soda -- a 7-row and an 8-cell int16 sum, a 6-row min
+  and a 6-cell max, iterate 3 -- through every window form of the backend: the
+  sliding sum along the streamed dimension (an int32 accumulator that lives
+  across row steps, set up at the stage's first step of a chunk), the
+  power-of-two chain (min along it; both directions on `direct`), the
+  dimension-0 windows reduced for all cells of a lane jointly; fused and not,
+  chunks that start in the peeled warm-up and in the loop.  Bit for bit."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path('winsum2d.soda'))
+  opts = lower.LowerOptions(fuse=fuse, strategy=strategy)
+  if strategy == 'auto':
+    src = lower.lower(stencil, opts).source
+    assert 'xa_t0_rows_r0' in src and 'xw_t0_cols' in src and 'xm_t0_hi' in src
+    assert 'in_min1_4' in src
+  _check(stencil, extent, opts, oracle='c')
+  for chunk in (5, 40):       # first step in the loop / deep in the warm-up
+    if strategy == 'auto':
+      _check(stencil, extent, lower.LowerOptions(fuse=fuse, chunk_rows=chunk,
+                                                 peel=0 if chunk == 5 else -1),
+             oracle='c', seed=chunk)
+
+
 @pytest.mark.parametrize('name,extent,fuse', [
     ('coupled2d.soda', (300, 90), (2,)),     # 2 inputs -> 2 outputs, iterate 3
     ('coupled2d.soda', (300, 90), ()),

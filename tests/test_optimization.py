@@ -104,7 +104,13 @@ def test_window_reductions_become_power_of_two_chains():
 
 
 def test_lowering_uses_the_derived_program_and_can_be_told_not_to():
+  from soda_amd import runtime
   from soda_amd.codegen.hip import lower
+  assert lower.MAX_TENSORS == runtime.MAX_TENSORS
+  # a program whose chains would not fit the argument block keeps its windows
+  w = core.from_file(soda_path('winsum2d.soda'))
+  d = lower.lower(w, lower.LowerOptions(strategy='direct', vec=1))
+  assert len(d.stencil.symbol_table) <= runtime.MAX_TENSORS
   st = core.from_file(soda_path('erosion.soda'))
   on = lower.lower(st, lower.LowerOptions(vec=4))
   off = lower.lower(st, lower.LowerOptions(vec=4, windows=False, inline=False))
