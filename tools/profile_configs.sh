@@ -22,6 +22,9 @@ run heat3d_t2 heat3d.soda 512 512 512 --iterate 20 --fuse 2 --reps 3 || exit 1
 run blur blur.soda 16384 16384 --reps 10 || exit 1
 run contrast contrast.soda 8192 8192 --reps 5 || exit 1
 run denoise2d denoise2d.soda 8192 8192 --reps 5 || exit 1
+run erosion erosion.soda 8192 8192 --reps 10 || exit 1
+run xcorr xcorr.soda 8192 8192 --reps 10 || exit 1
+run denoise3d denoise3d.soda 512 512 512 --reps 3 || exit 1
 python3 - <<PY
 import json, glob
 merged = {}
