@@ -90,6 +90,10 @@ def add_arguments(parser) -> None:
                       'grid into N slabs along the streamed dimension, one '
                       'per GPU, halo exchange by peer copies '
                       '(soda_hip_group_*)')
+  parser.add_argument('--hip-exchange-every', type=int, default=0,
+                      dest='hip_exchange_every', metavar='K',
+                      help='with --hip-gpus N: iterations between halo '
+                      'exchanges (default 0: the library picks)')
   parser.add_argument('--hip-virtual', action='store_true', dest='hip_virtual',
                       help='with --hip-gpus N: all N slabs on --hip-device '
                       '(the whole schedule on one GPU)')
@@ -186,7 +190,9 @@ def run(stencil: core.Stencil, args: argparse.Namespace) -> None:
     # one host thread, N GPUs: slabs along the streamed dimension
     devices = ([args.hip_device] * gpus if getattr(args, 'hip_virtual', False)
                else list(range(gpus)))
-    prog = runtime.Group(stencil, extent, devices, options_from_args(args))
+    prog = runtime.Group(stencil, extent, devices, options_from_args(args),
+                         exchange_every=int(getattr(args, 'hip_exchange_every',
+                                                    0) or 0))
     t0 = time.time()
     outputs = prog.run_host(inputs)
     seconds = time.time() - t0

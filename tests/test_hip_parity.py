@@ -421,6 +421,36 @@ def test_sodac_hip_backend_runs(built):
   assert out['checksum']['blur_y'] == float((p + q + 2)[:62, :1998].sum())
 
 
+def test_sodac_hip_backend_on_several_gpus(built):
+  """`sodac --hip-backend --hip-gpus N --hip-virtual`: the same program cut
+  into N slabs (soda_hip_group_*, here all on the one GPU), same checksum as on
+  one GPU -- blur (one shot) and heat3d (iterated: halo exchanges)."""
+  import json
+  import subprocess
+  import sys
+  from conftest import ROOT
+
+  def run(*flags):
+    r = subprocess.run([sys.executable, '-m', 'soda_amd.sodac', *flags],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+  blur = [soda_path('blur.soda'), '--hip-backend', '--hip-extent', '2000', '96']
+  one = run(*blur)
+  four = run(*blur, '--hip-gpus', '4', '--hip-virtual')
+  assert four['gpus'] == 4 and four['devices'] == [0] * 4
+  assert four['checksum'] == one['checksum']
+  heat = [soda_path('heat3d.soda'), '--iterate', '12', '--hip-fuse', '2',
+          '--hip-backend', '--hip-extent', '64', '48', '96']
+  one = run(*heat)
+  three = run(*heat, '--hip-gpus', '3', '--hip-virtual',
+              '--hip-exchange-every', '4')
+  assert (three['exchange_every'], three['exchanges']) == (4, 2)
+  assert three['split_passes'] > 0 and three['checksum'] == one['checksum']
+  assert any(v != 0 for v in one['checksum'].values())
+
+
 def test_blur_reference_init_closed_form(built):
   """blur on the reference harness's p+q input is p+q+2 (SURVEY 8c KAT)."""
   from soda_amd import core, runtime
