@@ -313,6 +313,36 @@ def test_one_enqueueing_thread_per_slab(built, name, extent, iterate, fuse,
   assert st['copies'] == rounds * 2 * (slabs - 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('threads', [True, False])
+def test_many_short_intervals_stay_in_order(built, threads):
+  """300 intervals of two iterations on 8 slabs, 60 chained runs: the event
+  chain (and, threaded, the hand-over of recorded events between the slabs'
+  enqueueing threads) must never let a copy or a pass overtake what it depends
+  on.  `border: preserve` keeps the whole grid defined, so every cell of the
+  600-iteration result is compared."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  extent = (256, 640)
+  runs, per_run = 60, 10
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=per_run,
+                           border='preserve')
+  inputs = _inputs(stencil, extent, 23)
+  with runtime.Group(stencil, extent, [0] * 8, lower.LowerOptions(fuse=(2,)),
+                     exchange_every=2, threads=threads) as group:
+    group.load(inputs)
+    for _ in range(runs):
+      group.run()
+    st = group.stats()
+    got = group.store(per_run)
+  assert (st['intervals'], st['exchanges']) == (5, 5)
+  total = core.from_file(soda_path('jacobi2d.soda'), iterate=runs * per_run,
+                         border='preserve')
+  want = c_oracle.COracle(total).run(inputs)
+  assert np.array_equal(got['t0'], want['t0'])
+
+
 C5 = ('jacobi2d.soda', (8192, 8192), 1000, (12, 4), 3)
 C4 = ('heat3d.soda', (512, 512, 512), 50, (2,), 2)
 
