@@ -355,8 +355,10 @@ def test_integer_window_forms(built, fuse, strategy, extent):
   from soda_amd.codegen.hip import lower
   stencil = core.from_file(soda_path('winsum2d.soda'))
   opts = lower.LowerOptions(fuse=fuse, strategy=strategy)
-  if strategy == 'auto':
-    src = lower.lower(stencil, opts).source
+  import os
+  if strategy == 'auto' and not (os.environ.get('SODA_HIP_WINDOWS') or
+                                 os.environ.get('SODA_HIP_SLIDE')):
+    src = lower.lower(stencil, opts).source       # (the defaults, not an A/B run)
     assert 'xa_t0_rows_r0' in src and 'xw_t0_cols' in src and 'xm_t0_hi' in src
     assert 'in_min1_4' in src
   _check(stencil, extent, opts, oracle='c')
