@@ -51,10 +51,11 @@ def parse_args():
       ROOT, 'tests', 'golden', 'soda', 'jacobi2d.soda'))
   ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])
   ap.add_argument('--iterate', type=int, default=100)
-  ap.add_argument('--fuse', type=int, nargs='+', default=[12, 8, 4],
-                  help='iterations fused per launch (temporal blocking); the '
-                  'first value is the dominant pass, the others serve the '
-                  'remainder of iterate')
+  ap.add_argument('--fuse', type=int, nargs='+', default=[13, 12, 8, 4],
+                  help='iterations one launch may fuse (temporal blocking); '
+                  'the library mixes the depths per extent so that they add '
+                  'up to iterate at the least total time (100 = 4 x 13 + '
+                  '4 x 12)')
   ap.add_argument('--chunk-rows', type=int, default=None,
                   help='rows per wave; default: sized per kernel and GPU')
   ap.add_argument('--prefetch', type=int, default=None)
@@ -460,13 +461,41 @@ def main():
   for e in local_extent:
     local_cells *= e
 
-  # the dominant kernel exactly as the step runs it: `per_call` launches in a
-  # row, state rotating through the program's work arrays (a kernel that
-  # re-reads ONE input array from the 256 MiB Infinity Cache times differently)
-  per_call = max(1, args.iterate // fuse) if fuse > 1 else 8
+  # The dominant kernel = the scheduled pass with the largest share of a
+  # step's time (the schedule may mix depths: 100 = 4 x 13 + 4 x 12), timed
+  # exactly as the step runs it: `per_call` launches in a row, state rotating
+  # through the program's work arrays (a kernel that re-reads ONE input array
+  # from the 256 MiB Infinity Cache times differently).  The run entry only
+  # takes an iteration count, so the count is chosen such that the library's
+  # schedule for it consists of that pass alone.
+  interval = min(ex, args.iterate)
+  sched = prog.schedule(local_extent, interval)
+  cal_us = prog.pass_times(local_extent)[0]
+
+  def pure_calls(depth):
+    n = max(1, args.iterate // depth) if depth > 1 else 8
+    while n > 1 and prog.schedule(local_extent, depth * n) != {depth: n}:
+      n -= 1
+    return n
+
+  fuse_deepest = fuse
+  fuse = max(sched, key=lambda t: sched[t] * cal_us.get(t, float(t)))
+  per_call = pure_calls(fuse)
+  if prog.schedule(local_extent, fuse * per_call) != {fuse: per_call}:
+    raise SystemExit('cannot time pass T=%d alone' % fuse)
 
   def dominant():
     step_fn(b_bufs, a_bufs, local_extent, fuse * per_call)
+
+  def time_pass(depth):
+    n = pure_calls(depth)
+    if prog.schedule(local_extent, depth * n) != {depth: n}:
+      return None
+
+    def go():
+      step_fn(b_bufs, a_bufs, local_extent, depth * n)
+    go()
+    return time_events(go, stream, max(1, 24 // n)) / n
 
   dominant()
   torch.cuda.synchronize()
@@ -519,10 +548,11 @@ def main():
   kernel_key = runtime.source_key(prog.module.source)
   roofline['kernel_key'] = kernel_key
   traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
+  traffic_table = {}
   if os.path.exists(traffic_file):
     try:
       with open(traffic_file) as f:
-        measured = json.load(f)
+        measured = traffic_table = json.load(f)
       if kname in measured and measured[kname].get('kernel_key') != kernel_key:
         roofline['traffic_dropped'] = (
             'profiles/traffic.json holds %s for key %s; this run built key %s'
@@ -628,6 +658,25 @@ def main():
   })
   if roofline.get('measured_copy_GBs'):
     roofline['frac_of_measured_copy'] = achieved / roofline['measured_copy_GBs']
+  # every pass of the step's schedule, timed the same way (the dominant one is
+  # the object above)
+  scheduled = []
+  for depth, count in sorted(sched.items(), reverse=True):
+    ms = kernel_ms if depth == fuse else time_pass(depth)
+    ps = [p for p in prog.module.sorted_passes() if p.fused_iters == depth]
+    name = prog.module.kernels[ps[0].kernels[0]].name if ps else '?'
+    pmc = traffic_table.get(name) or {}
+    scheduled.append({
+        'kernel': name,
+        'traffic': pmc.get('hbm_bytes_per_launch')
+                   if pmc.get('kernel_key') == kernel_key else None,
+        'iterations_per_launch': depth,
+        'launches_per_exchange_interval': count,
+        'kernel_ms': ms,
+        'frac': alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
+    })
+  torch.cuda.synchronize()
+  roofline['scheduled_kernels'] = scheduled
   if 'valu' in roofline:
     roofline['valu']['frac_of_valu_issue_peak'] = (
         roofline['valu']['min_issue_ms'] / kernel_ms)

@@ -355,11 +355,12 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi);
 
-/* Measures one launch of every pass on `extent` (stand-in arrays, `launches`
- * back-to-back launches per pass, HIP events on `stream`; synchronises) and
+/* Measures one launch of every pass on `extent` (stand-in arrays; two warming
+ * rounds, then four rounds of `launches` back-to-back launches per pass inside
+ * HIP events on `stream`, the shortest round counts; synchronises) and
  * remembers the times: later runs on exactly this extent schedule their passes
- * by the clock instead of the model.  Costs a few milliseconds once; programs
- * with a single pass have nothing to choose and return at once. */
+ * by the clock instead of the model.  Costs milliseconds, once; programs with
+ * a single pass have nothing to choose and return at once. */
 int soda_hip_program_calibrate(soda_hip_program_t* program,
                                const int32_t* extent, int32_t launches,
                                void* stream);

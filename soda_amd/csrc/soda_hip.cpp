@@ -1185,14 +1185,20 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipMemsetAsync");
   }
   std::vector<double> ns(plan.num_passes, 0.0);
-  // Two rounds over all the passes bring the clocks to what a long run holds
-  // (a burst of launches a millisecond after idle reads 20-30 % slow, and not
-  // equally per pass); then every pass runs twice back to back, the second
-  // run inside an event pair -- a schedule runs a pass many times in a row,
-  // and the first launches behind a different kernel are not representative
-  // (jacobi2d T = 12 right behind the memory-bound T = 1: 167 us, sustained
-  // 146).  Nothing synchronises in between, so the GPU never idles.
-  std::vector<hipEvent_t> ev(2 * plan.num_passes, nullptr);
+  // Two rounds over all the passes bring the clocks up (a burst of launches a
+  // millisecond after idle reads 20-30 % slow, and not equally per pass: the
+  // issue-bound deep passes follow the core clock, the memory-bound shallow
+  // ones do not); then kTimedRounds rounds in which every pass runs once
+  // untimed and `launches` times inside an event pair -- a schedule runs a
+  // pass many times in a row, and the first launch behind a different kernel
+  // is not representative (jacobi2d T = 12 right behind the memory-bound
+  // T = 1: 167 us, sustained 146).  A pass's time is the SHORTEST of its
+  // rounds: the clocks keep rising through the first milliseconds, and one
+  // round alone priced T = 13 at 161-173 us (sustained 144), enough to flip
+  // the schedule of 100 iterations between 4 x 13 + 4 x 12 and 7 x 12 + 2 x 8
+  // from run to run.  Nothing synchronises in between, so the GPU never idles.
+  constexpr int kTimedRounds = 4;
+  std::vector<hipEvent_t> ev(2 * plan.num_passes * kTimedRounds, nullptr);
   for (auto& e : ev)
     if (rc == SODA_HIP_OK && hipEventCreate(&e) != hipSuccess)
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventCreate");
@@ -1207,24 +1213,29 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
         rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
                       plan.passes[i].fused_iters * launches, stream_, i,
                       nullptr);
-    for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
-      const int32_t iters = plan.passes[i].fused_iters * launches;
-      rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
-                    iters, stream_, i, nullptr);
-      if (rc != SODA_HIP_OK) break;
-      (void)hipEventRecord(ev[2 * i], stream);
-      rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
-                    iters, stream_, i, nullptr);
-      (void)hipEventRecord(ev[2 * i + 1], stream);
-    }
+    for (int round = 0; round < kTimedRounds && rc == SODA_HIP_OK; ++round)
+      for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
+        const int32_t one = plan.passes[i].fused_iters;
+        hipEvent_t* pair = &ev[2 * (round * plan.num_passes + i)];
+        rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
+                      one, stream_, i, nullptr);
+        if (rc != SODA_HIP_OK) break;
+        (void)hipEventRecord(pair[0], stream);
+        rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
+                      one * launches, stream_, i, nullptr);
+        (void)hipEventRecord(pair[1], stream);
+      }
     if (rc == SODA_HIP_OK && hipStreamSynchronize(stream) != hipSuccess)
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipStreamSynchronize");
-    for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess)
-        rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventElapsedTime");
-      ns[i] = ms * 1e6 / launches;
-    }
+    for (int i = 0; i < plan.num_passes && rc == SODA_HIP_OK; ++i)
+      for (int round = 0; round < kTimedRounds && rc == SODA_HIP_OK; ++round) {
+        float ms = 0;
+        hipEvent_t* pair = &ev[2 * (round * plan.num_passes + i)];
+        if (hipEventElapsedTime(&ms, pair[0], pair[1]) != hipSuccess)
+          rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventElapsedTime");
+        const double t = ms * 1e6 / launches;
+        if (round == 0 || t < ns[i]) ns[i] = t;
+      }
   }
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);

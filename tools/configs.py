@@ -76,14 +76,14 @@ def main():
   out = []
   out.append(measure('blur.soda', (2000, 1024), 1, (), label='C1 blur 2000x1024 (GPU run of the CPU plumbing case)', reps=50))
   out.append(measure('jacobi2d.soda', (8192, 8192), 100, (), label='C2 jacobi2d 8192^2 it=100, one iteration per launch'))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 8, 4), label='C2 jacobi2d 8192^2 it=100, T=12 fused'))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (13, 12, 8, 4), label='C2 jacobi2d 8192^2 it=100, T=12 fused'))
   out.append(measure('blur.soda', (16384, 16384), 1, (), label='C3 blur 16384^2 fused two-stage', reps=20))
   out.append(measure('heat3d.soda', (512, 512, 512), 50, (), label='C4 heat3d 512^3 it=50, one iteration per launch, 1 GPU'))
   out.append(measure('heat3d.soda', (512, 512, 512), 50, (2,), label='C4 heat3d 512^3 it=50, T=2 fused, 1 GPU'))
   out.append(measure('heat3d.soda', (512, 512, 512), 50, (2,), world=8, label='C4 heat3d 512^3 it=50, T=2, slab of an 8-GPU run (compute only, exchanges not timed)'))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 8, 4), label='C5 jacobi2d 8192^2 it=1000, T=12 fused, 1 GPU', reps=2))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (12, 8, 4), world=8, label='C2 jacobi2d 8192^2 it=100, slab of an 8-GPU run (exchange-free)'))
-  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (12, 8, 4), world=8, label='C5 jacobi2d 8192^2 it=1000, slab of an 8-GPU run (compute only, exchanges not timed)', reps=2))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (13, 12, 8, 4), label='C5 jacobi2d 8192^2 it=1000, T=12 fused, 1 GPU', reps=2))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 100, (13, 12, 8, 4), world=8, label='C2 jacobi2d 8192^2 it=100, slab of an 8-GPU run (exchange-free)'))
+  out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (13, 12, 8, 4), world=8, label='C5 jacobi2d 8192^2 it=1000, slab of an 8-GPU run (compute only, exchanges not timed)', reps=2))
   out.append(measure('jacobi2d.soda', (8192, 8192), 1000, (4,), label='C5 jacobi2d 8192^2 it=1000, T=4 fused (as BASELINE words it), 1 GPU', reps=2))
   for r in out:
     print(json.dumps(r))

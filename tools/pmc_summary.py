@@ -76,7 +76,12 @@ def main():
     with open(sys.argv[6]) as f:
       line = [l for l in f.read().splitlines() if l.startswith('{')][-1]
     bench = json.loads(line)
-    pairs = [(bench['roofline'].get('kernel'), bench['roofline'].get('kernel_key'))]
+    roof = bench['roofline']
+    # the step's passes live in one module (one key); the single-iteration leg
+    # builds its own
+    pairs = [(k.get('kernel'), roof.get('kernel_key'))
+             for k in roof.get('scheduled_kernels', [])]
+    pairs.append((roof.get('kernel'), roof.get('kernel_key')))
     si = bench.get('single_iter') or {}
     pairs.append((si.get('kernel'), si.get('kernel_key')))
     for name, key in pairs:
