@@ -1459,9 +1459,13 @@ class _MarchKernel:
       +        out[0] = the first window, out[e + 1] = out[e] + in[e + taps]
                - in[e]: taps - 1 + 2 (V - 1) operations for V cells, in int32
                (exact: the values are narrower than 32 bits, windows.py);
-      min/max  the windows share the middle block in[V-1 .. taps-1]; suffix
-               reductions of in[0 .. V-2] and prefix reductions of
-               in[taps .. taps+V-2] complete them: ~ taps + 3 V operations.
+      min/max  in blocks of b = min(V, taps) cells: the windows of a block
+               share the middle cells in[e0+b-1 .. e0+taps-1]; suffix
+               reductions of in[e0 .. e0+b-2] and prefix reductions of
+               in[e0+taps .. e0+taps+b-2] complete them: ~ taps + 3 b
+               operations per block.  (One block only when V <= taps; with
+               more cells per lane than taps -- uint8: 16 -- no cell is common
+               to all V windows.)
 
     Integer arithmetic in any order gives the same bits as the statement's
     left-to-right text; the statement's cast is applied per cell as before."""
@@ -1487,41 +1491,44 @@ class _MarchKernel:
       else:
         fn = 'SODA_MIN' if op == 'min' else 'SODA_MAX'
         pt = self.st.symbol_table[pname].c_type
-        lo, hi = V - 1, taps - 1            # cells every window contains
-        if lo > hi:                         # (more cells per lane than taps)
-          lo, hi = hi, hi
-        mid = '(%s)%s' % (pt, cells[lo])
-        for c in cells[lo + 1:hi + 1]:
-          mid = '%s((%s)%s, %s)' % (fn, pt, c, mid)
-        body.append('        const %s xm_%s = %s;' % (pt, tag, mid))
-        # suffix reductions of the cells below the middle block ...
-        suf = {}
-        prev = None
-        for i in range(lo - 1, -1, -1):
-          name = 'xs_%s_%d' % (tag, i)
-          expr = '(%s)%s' % (pt, cells[i]) if prev is None else \
-              '%s((%s)%s, %s)' % (fn, pt, cells[i], prev)
-          body.append('        const %s %s = %s;' % (pt, name, expr))
-          suf[i] = prev = name
-        # ... and prefix reductions of the cells above it
-        pre = {}
-        prev = None
-        for i in range(hi + 1, V + taps - 1):
-          name = 'xp_%s_%d' % (tag, i)
-          expr = '(%s)%s' % (pt, cells[i]) if prev is None else \
-              '%s(%s, (%s)%s)' % (fn, prev, pt, cells[i])
-          body.append('        const %s %s = %s;' % (pt, name, expr))
-          pre[i] = prev = name
-        for e in range(V):
-          parts = ['xm_%s' % tag]
-          if e < lo:
-            parts.append(suf[e])
-          if e + taps - 1 > hi:
-            parts.append(pre[e + taps - 1])
-          expr = parts[0]
-          for q in parts[1:]:
-            expr = '%s(%s, %s)' % (fn, expr, q)
-          body.append('        %s = (%s)(%s);' % (dst[e], n.ctype, expr))
+        # blocks of at most `taps` cells: the windows of cells e0 .. e0+b-1
+        # all contain in[e0+b-1 .. e0+taps-1] (b <= taps, so never empty)
+        for blk, e0 in enumerate(range(0, V, taps)):
+          b = min(taps, V - e0)
+          lo, hi = e0 + b - 1, e0 + taps - 1
+          btag = '%s_b%d' % (tag, blk)
+          mid = '(%s)%s' % (pt, cells[lo])
+          for c in cells[lo + 1:hi + 1]:
+            mid = '%s((%s)%s, %s)' % (fn, pt, c, mid)
+          body.append('        const %s xm_%s = %s;' % (pt, btag, mid))
+          # suffix reductions of the cells below the middle block ...
+          suf = {}
+          prev = None
+          for i in range(lo - 1, e0 - 1, -1):
+            name = 'xs_%s_%d' % (btag, i)
+            expr = '(%s)%s' % (pt, cells[i]) if prev is None else \
+                '%s((%s)%s, %s)' % (fn, pt, cells[i], prev)
+            body.append('        const %s %s = %s;' % (pt, name, expr))
+            suf[i] = prev = name
+          # ... and prefix reductions of the cells above it
+          pre = {}
+          prev = None
+          for i in range(hi + 1, e0 + b + taps - 1):
+            name = 'xp_%s_%d' % (btag, i)
+            expr = '(%s)%s' % (pt, cells[i]) if prev is None else \
+                '%s(%s, (%s)%s)' % (fn, prev, pt, cells[i])
+            body.append('        const %s %s = %s;' % (pt, name, expr))
+            pre[i] = prev = name
+          for e in range(e0, e0 + b):
+            parts = ['xm_%s' % btag]
+            if e < lo:
+              parts.append(suf[e])
+            if e + taps - 1 > hi:
+              parts.append(pre[e + taps - 1])
+            expr = parts[0]
+            for q in parts[1:]:
+              expr = '%s(%s, %s)' % (fn, expr, q)
+            body.append('        %s = (%s)(%s);' % (dst[e], n.ctype, expr))
       body.append('      }')
 
   def _emit_store(self, n: _Node, oname: str, dst_slot: int) -> None:

@@ -136,3 +136,72 @@ def inputs_for(stencil, extent, seed: int):
       hi = min(int(np.iinfo(dt).max), 200)
       out[name] = rng.integers(0, hi + 1, shape).astype(dt)
   return out
+
+
+WINDOW_TYPES = ['int16', 'uint16', 'uint8', 'int32']
+
+
+def window_program(seed: int):
+  """Random programs made of integer window reductions (sums, min, max over
+  2-24 contiguous taps along one dimension, chained 1-3 stages deep, random
+  first offsets and store indices, narrow types whose sums wrap in the cast):
+  the shapes the backend evaluates as sliding sums, power-of-two chains and
+  joint per-lane windows instead of tap by tap.  Returns (text, dim, iterate)."""
+  rng = np.random.default_rng(seed + 77000)
+  dim = int(rng.choice([2, 2, 2, 3]))
+  t = WINDOW_TYPES[int(rng.integers(len(WINDOW_TYPES)))]
+  iterate = int(rng.choice([1, 1, 2, 3]))
+  longest = 24 if dim == 2 else 8
+  lines = ['kernel: wfuzz%d' % seed, 'burst width: 64', 'unroll factor: 2',
+           'iterate: %d' % iterate,
+           'input %s: in0(%s, *)' % (t, ', '.join(['32'] * (dim - 1)))]
+  n_stage = int(rng.integers(1, 4))
+  produced = ['in0']
+  for k in range(n_stage):
+    parent = produced[-1] if rng.random() < 0.7 else \
+        produced[int(rng.integers(len(produced)))]
+    op = ['+', 'min', 'max'][int(rng.integers(3))]
+    d = int(rng.integers(dim))
+    n = int(rng.integers(2, longest + 1))
+    first = int(rng.integers(-n + 1, 2))
+    base = [int(rng.integers(-1, 2)) if rng.random() < 0.2 else 0
+            for _ in range(dim)]
+    taps = []
+    for j in range(n):
+      idx = list(base)
+      idx[d] = first + j
+      taps.append(_ref(parent, idx))
+    if rng.random() < 0.15:           # not a contiguous run: left as written
+      taps.pop(int(rng.integers(len(taps))))
+    if rng.random() < 0.2:
+      order = rng.permutation(len(taps))
+      taps = [taps[int(i)] for i in order]
+    body = ' + '.join(taps) if op == '+' else '%s(%s)' % (op, ', '.join(taps)) \
+        if len(taps) > 1 else taps[0]
+    st_idx = _idx(rng, dim, 1) if rng.random() < 0.3 else (0,) * dim
+    last = k == n_stage - 1
+    if last:
+      extra = produced[int(rng.integers(len(produced)))]
+      r = rng.random()
+      if r < 0.3:
+        body = '(%s) / %d + %s' % (body, int(rng.integers(2, 9)),
+                                   _ref(extra, _idx(rng, dim, 1)))
+      elif r < 0.5:
+        body = '(%s) / %d' % (body, int(rng.integers(2, 9)))
+      lines.append('output %s: out0%s = %s' %
+                   (t, '(%s)' % ', '.join(map(str, st_idx)), body))
+    else:
+      name = 'w%d' % k
+      lt = t if rng.random() < 0.7 else \
+          WINDOW_TYPES[int(rng.integers(len(WINDOW_TYPES)))]
+      lines.append('local %s: %s = %s' % (lt, _ref(name, st_idx), body))
+      produced.append(name)
+  return '\n'.join(lines) + '\n', dim, iterate
+
+
+def window_extent_for(seed: int, dim: int):
+  rng = np.random.default_rng(seed + 78000)
+  if dim == 2:
+    return (int(rng.choice([128, 258, 300, 520])), int(rng.integers(80, 200)))
+  return (int(rng.choice([64, 130, 260])), int(rng.integers(24, 40)),
+          int(rng.integers(30, 60)))

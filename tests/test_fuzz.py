@@ -157,3 +157,82 @@ def test_gpu_matches_oracle_with_shared_rows(built, seed):
     got = prog.run(ins)
   for o in kept.output_names:     # the WHOLE grid is defined
     assert np.array_equal(got[o], want[o], equal_nan=True), (seed, o, text)
+
+
+# -- integer window reductions (tests/fuzz.py window_program) -----------------
+WINDOW_CPU_SEEDS = range(0, 24)
+# (109, 177, 283, 326, 454: found by tools/fuzz_scan.py -- min / max windows
+# along dimension 0 with fewer taps than the lane holds cells, uint8 at 16 cells
+# per lane, where no cell is common to all of a lane's windows)
+WINDOW_GPU_SEEDS = list(range(0, 80)) + [109, 177, 283, 326, 454]
+
+
+def _build_window(seed):
+  text, dim, iterate = fuzz.window_program(seed)
+  stencil = core.from_text(text)
+  extent = fuzz.window_extent_for(seed, dim)
+  lo, hi = stencil.valid_box(extent)
+  if not all(h > l for l, h in zip(lo, hi)):
+    pytest.skip('empty valid box')
+  return text, stencil, extent
+
+
+@pytest.mark.parametrize('seed', WINDOW_CPU_SEEDS)
+def test_oracles_agree_on_window_programs(seed):
+  from oracle import c_oracle, numpy_oracle
+  text, stencil, extent = _build_window(seed)
+  small = tuple(min(e, 70) for e in extent)
+  lo, hi = stencil.valid_box(small)
+  if not all(h > l for l, h in zip(lo, hi)):
+    small = extent
+  ins = fuzz.inputs_for(stencil, small, seed)
+  a = numpy_oracle.run(stencil, ins)
+  b = c_oracle.COracle(stencil, openmp=False).run(ins)
+  for o in stencil.output_names:
+    assert np.array_equal(a[o], b[o]), text
+
+
+def test_window_generator_reaches_every_window_form():
+  """Across the GPU seeds the lowering emits each of its window forms: sliding
+  sums (xa_), joint per-lane sums (xw_) and min / max (xm_), power-of-two
+  chains (<parent>_min<d>_<size> ...) -- and leaves some windows as written."""
+  import os
+  import re
+  from soda_amd.codegen.hip import lower
+  if os.environ.get('SODA_HIP_WINDOWS') or os.environ.get('SODA_HIP_SLIDE'):
+    pytest.skip('an A/B run with a window form switched off')
+  seen = set()
+  plain = 0
+  for seed in WINDOW_GPU_SEEDS:
+    text, dim, _ = fuzz.window_program(seed)
+    src = lower.lower(core.from_text(text), lower.LowerOptions(fuse=(2,))).source
+    found = {f for f in ('xa_', 'xw_', 'xm_') if f in src}
+    found |= {m.group(1) for m in re.finditer(r'_(min|max|sum)\d_\d+', src)}
+    seen |= found
+    plain += not found
+  assert seen >= {'xa_', 'xw_', 'xm_', 'min', 'max'}, seen
+  assert plain > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', WINDOW_GPU_SEEDS)
+def test_gpu_matches_oracle_on_window_programs(built, seed):
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  text, stencil, extent = _build_window(seed)
+  ins = fuzz.inputs_for(stencil, extent, seed)
+  want = c_oracle.COracle(stencil, openmp=False).run(ins)
+  for strategy in ('auto', 'direct'):
+    with runtime.Program(stencil, lower.LowerOptions(strategy=strategy,
+                                                     fuse=(2,)),
+                         extent=extent) as prog:
+      got = prog.run(ins)
+      kinds = sorted({p.kind for p in prog.module.passes})
+    for o in stencil.output_names:
+      lo, hi = stencil.valid_box(extent, o)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      g, w = got[o][idx], want[o][idx]
+      assert np.array_equal(g, w), (
+          'seed %d, %s (%s), output %s: %d cells differ\n%s' %
+          (seed, strategy, kinds, o, int((g != w).sum()), text))
