@@ -47,9 +47,55 @@ def _expr(rng, leaves, is_float, depth=0):
                         int(rng.integers(2, 7)))
 
 
-def program(seed: int):
-  """Returns (soda text, dim, iterate)."""
-  rng = np.random.default_rng(seed)
+def _expr_rich(rng, leaves, is_float, depth=0, to_int=True):
+  """As _expr, plus the rest of the operator set whose results are defined bit
+  for bit on both sides: float division (IEEE), unary minus, abs / fabs,
+  floor / ceil, select over comparisons and logic, casts between the float
+  types and to integers and back (`to_int`), integer %, &, |, ^ and 64-bit
+  detours."""
+  sub = lambda: _expr_rich(rng, leaves, is_float, depth + 1, to_int)
+  r = rng.random()
+  if depth >= 3 or r < 0.22:
+    return leaves[int(rng.integers(len(leaves)))]()
+  if r < 0.55:
+    return _expr(rng, [sub], is_float, 2 if depth >= 2 else 1)
+  if r < 0.63:
+    cmp_op = ['<', '<=', '>', '>=', '==', '!='][int(rng.integers(6))]
+    cond = '%s %s %s' % (sub(), cmp_op, sub())
+    if rng.random() < 0.3:
+      cond = '(%s) %s (%s %s %s)' % (cond, ['&&', '||'][int(rng.integers(2))],
+                                     sub(), ['<', '>'][int(rng.integers(2))],
+                                     sub())
+    return 'select(%s, %s, %s)' % (cond, sub(), sub())
+  if r < 0.70:
+    return '(-%s)' % sub()
+  if r < 0.76:
+    return '%s(%s)' % ('abs' if not is_float or rng.random() < 0.5 else 'fabs',
+                       sub())
+  if is_float:
+    if r < 0.86:
+      d = sub()
+      return '(%s / (1.5f + %s * %s))' % (sub(), d, d)
+    if r < 0.91:
+      return '%s(%s * 3.7f)' % (['floor', 'ceil'][int(rng.integers(2))], sub())
+    if r < 0.96:
+      return '%s(%s)' % (['float', 'double'][int(rng.integers(2))], sub())
+    if not to_int:     # (out of int32's range the conversion is undefined in
+      return sub()     # C: iterated programs, whose values grow, do without)
+    return 'float(int32(%s * 5.0f))' % sub()
+  if r < 0.84:
+    return '(%s %% %d)' % (sub(), int(rng.integers(2, 9)))
+  if r < 0.93:
+    return '(%s %s %s)' % (sub(), ['&', '|', '^'][int(rng.integers(3))], sub())
+  return 'int32(int64(%s) * 100003 %% 1009)' % sub()
+
+
+def program(seed: int, rich: bool = False):
+  """Returns (soda text, dim, iterate).  `rich`: the wider operator set of
+  _expr_rich (its own seeds: the programs of the plain generator never
+  change)."""
+  rng = np.random.default_rng(seed + 555000 if rich else seed)
+  _gen = _expr
   dim = int(rng.choice([1, 2, 2, 2, 3]))
   is_float = bool(rng.random() < 0.6)
   types = FLOAT_TYPES if is_float else INT_TYPES
@@ -62,10 +108,13 @@ def program(seed: int):
   else:
     out_types = [types[int(rng.integers(len(types)))] for _ in range(n_out)]
   iterate = int(rng.choice([1, 2, 3])) if iterable else 1
+  if rich:
+    def _gen(r, leaves, flt, depth=0, _to_int=iterate == 1):
+      return _expr_rich(r, leaves, flt, depth, _to_int)
   radius = 1 if dim == 3 else int(rng.choice([1, 2]))
   tile = ['32'] * (dim - 1)
-  lines = ['kernel: fuzz%d' % seed, 'burst width: 64', 'unroll factor: 2',
-           'iterate: %d' % iterate]
+  lines = ['kernel: %sfuzz%d' % ('r' if rich else '', seed),
+           'burst width: 64', 'unroll factor: 2', 'iterate: %d' % iterate]
   names = []
   for i, t in enumerate(in_types):
     decl = 'in%d' % i
@@ -94,14 +143,14 @@ def program(seed: int):
     lets = []
     if rng.random() < 0.3:
       lt = t
-      lets.append('  %s tmp = %s' % (lt, _expr(rng, [leaf], is_float, 1)))
+      lets.append('  %s tmp = %s' % (lt, _gen(rng, [leaf], is_float, 1)))
       leaves.append(lambda: 'tmp')
     if is_float:
       leaves.append(lambda: '%.3ff' % rng.uniform(-1.0, 1.0)
                     if t == 'float' else '%.3f' % rng.uniform(-1.0, 1.0))
     else:
       leaves.append(lambda: str(int(rng.integers(0, 50))))
-    body = _expr(rng, leaves, is_float)
+    body = _gen(rng, leaves, is_float)
     head = ('output %s:' if is_out else 'local %s:') % t
     if lets:
       lines.append(head)

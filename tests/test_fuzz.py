@@ -236,3 +236,64 @@ def test_gpu_matches_oracle_on_window_programs(built, seed):
       assert np.array_equal(g, w), (
           'seed %d, %s (%s), output %s: %d cells differ\n%s' %
           (seed, strategy, kinds, o, int((g != w).sum()), text))
+
+
+# -- the wider operator set (tests/fuzz.py _expr_rich) ------------------------
+RICH_CPU_SEEDS = range(0, 40)
+RICH_GPU_SEEDS = range(0, 120)
+
+
+def _build_rich(seed):
+  text, dim, iterate = fuzz.program(seed, rich=True)
+  try:
+    stencil = core.from_text(text)
+  except util.SodaError:
+    pytest.skip('generator produced an invalid program')
+  extent = fuzz.extent_for(seed, dim)
+  lo, hi = stencil.valid_box(extent)
+  if not all(h > l for l, h in zip(lo, hi)):
+    pytest.skip('empty valid box')
+  return text, stencil, extent
+
+
+@pytest.mark.parametrize('seed', RICH_CPU_SEEDS)
+def test_oracles_agree_on_rich_programs(seed):
+  from oracle import c_oracle, numpy_oracle
+  text, stencil, extent = _build_rich(seed)
+  ins = fuzz.inputs_for(stencil, extent, seed)
+  a = numpy_oracle.run(stencil, ins)
+  b = c_oracle.COracle(stencil, openmp=False).run(ins)
+  for o in stencil.output_names:
+    assert np.array_equal(a[o], b[o], equal_nan=True), text
+
+
+def test_rich_generator_covers_the_operators():
+  blob = '\n'.join(fuzz.program(s, rich=True)[0] for s in RICH_GPU_SEEDS)
+  for needle in ('select(', ' / (1.5f', '(-', 'abs(', 'fabs(', 'floor(',
+                 'ceil(', 'double(', 'int32(', 'int64(', ' % ', ' & ', ' | ',
+                 ' ^ ', '&&', '||', ' <= ', ' != '):
+    assert needle in blob, needle
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', RICH_GPU_SEEDS)
+def test_gpu_matches_oracle_on_rich_programs(built, seed):
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  text, stencil, extent = _build_rich(seed)
+  ins = fuzz.inputs_for(stencil, extent, seed)
+  want = c_oracle.COracle(stencil, openmp=False).run(ins)
+  for strategy in ('auto', 'direct'):
+    with runtime.Program(stencil, lower.LowerOptions(strategy=strategy,
+                                                     fuse=(2,)),
+                         extent=extent) as prog:
+      got = prog.run(ins)
+      kinds = sorted({p.kind for p in prog.module.passes})
+    for o in stencil.output_names:
+      lo, hi = stencil.valid_box(extent, o)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      g, w = got[o][idx], want[o][idx]
+      assert np.array_equal(g, w, equal_nan=True), (
+          'seed %d, %s (%s), output %s: %d cells differ\n%s' %
+          (seed, strategy, kinds, o, int((g != w).sum()), text))

@@ -2,7 +2,7 @@
 """One-off scan of random programs beyond the seeds the test suite holds: the
 generic generator (tests/fuzz.py program) and the window generator
 (window_program), GPU kernels (auto and direct) against the C oracle, bit for
-bit.  Usage: python tools/fuzz_scan.py window|generic FIRST LAST"""
+bit.  Usage: python tools/fuzz_scan.py window|generic|rich FIRST LAST"""
 import os
 import sys
 import time
@@ -20,7 +20,9 @@ def main():
   from soda_amd import core, runtime, util
   from soda_amd.codegen.hip import lower
   kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-  gen = fuzz.window_program if kind == 'window' else fuzz.program
+  gen = (fuzz.window_program if kind == 'window' else
+         (lambda s: fuzz.program(s, rich=True)) if kind == 'rich' else
+         fuzz.program)
   ext_for = fuzz.window_extent_for if kind == 'window' else fuzz.extent_for
   ran = failed = 0
   t0 = time.time()
