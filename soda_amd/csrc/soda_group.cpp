@@ -53,6 +53,8 @@ struct Slab {
   hipStream_t main = nullptr, comm = nullptr;
   hipEvent_t ghosts_ready[2] = {nullptr, nullptr};   // by interval parity
   hipEvent_t sendable[2] = {nullptr, nullptr};
+  // the interval whose exchange recorded ghosts_ready[parity] last (-1: none)
+  int64_t exchanged_at[2] = {-1, -1};
   // intervals whose launches (and `sendable` record) are enqueued: what a
   // neighbour's enqueueing thread waits for before it orders a copy behind them
   std::atomic<int64_t> enqueued{0};
@@ -344,6 +346,7 @@ int enqueue_exchange(soda_hip_group* g, int s, int64_t j) {
     }
   }
   HIP_TRY(hipEventRecord(me.ghosts_ready[j & 1], me.comm));
+  me.exchanged_at[j & 1] = j;
   return SODA_HIP_OK;
 }
 
@@ -369,6 +372,21 @@ int enqueue_interval(soda_hip_group* g, int s, int64_t j, int32_t iters,
     after = run.sendable;
     run.ghosts_ready = run.sendable = nullptr;
     run.ghost_lo = run.ghost_hi = run.send_lo = run.send_hi = 0;
+  }
+  // This interval writes the arrays interval j - 1 read -- and exchange j - 1
+  // copied the neighbours' ghost rows OUT of.  Those copies run on the
+  // neighbours' streams; when the reach is two-sided they are ordered ahead of
+  // this interval by the chain copy -> the neighbour's interval j - 1 -> its
+  // `sendable` -> my exchange j, but a neighbour I never fetch from (one-sided
+  // reach: the program taps upward only, say) puts nothing in my way, and I
+  // could overwrite rows it has not fetched yet -- seen as two wrong planes
+  // once in ~300 random groups (tools/fuzz_scan.py group).  So: behind them.
+  for (int peer = s - 1; j >= 1 && peer <= s + 1; peer += 2) {
+    if (peer < 0 || peer >= n) continue;
+    Slab& nb = *g->slabs[peer];
+    const int32_t fetched = peer < s ? nb.ghost_hi : nb.ghost_lo;
+    if (fetched > 0 && nb.exchanged_at[(j - 1) & 1] == j - 1)
+      HIP_TRY(hipStreamWaitEvent(me.main, nb.ghosts_ready[(j - 1) & 1], 0));
   }
   const std::vector<void*>& cur = g->inputs_of(me, j);
   std::vector<const void*> ins(cur.begin(), cur.end());

@@ -343,6 +343,48 @@ def test_many_short_intervals_stay_in_order(built, threads):
   assert np.array_equal(got['t0'], want['t0'])
 
 
+ONE_SIDED = """kernel: upwind
+burst width: 64
+unroll factor: 2
+iterate: 4
+input float: u(64, *)
+output float: v(0, 0) = (u(0, 0) + u(0, 1) + u(-1, 0) + u(1, 1)) * 0.25f
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('threads', [True, False])
+@pytest.mark.parametrize('overlap', [True, False])
+def test_one_sided_reach_orders_writes_behind_the_neighbours_copies(
+    built, threads, overlap):
+  """A program that taps upward only: a slab fetches ghost rows from the slab
+  above and never from the one below, so nothing in its own dependency chain
+  keeps it from running ahead and overwriting rows the slab below has not
+  copied yet (found by tools/fuzz_scan.py group: two wrong planes, one run in
+  hundreds).  400 intervals of one iteration on 6 uneven slabs, the whole grid
+  compared (`border: preserve`)."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  extent = (512, 227)
+  runs, per_run = 40, 10
+  stencil = core.from_text(ONE_SIDED, iterate=per_run, border='preserve')
+  assert stencil.reach_along(1) == (0, 1)
+  inputs = _inputs(stencil, extent, 5)
+  with runtime.Group(stencil, extent, [0] * 6, lower.LowerOptions(fuse=(2,)),
+                     exchange_every=1, threads=threads,
+                     overlap=overlap) as group:
+    assert group.slab(0).ghost_lo == 0 and group.slab(0).ghost_hi == 1
+    assert group.slab(5).ghost_lo == 0 and group.slab(5).ghost_hi == 0
+    group.load(inputs)
+    for _ in range(runs):
+      group.run()
+    got = group.store(per_run)
+  total = core.from_text(ONE_SIDED, iterate=runs * per_run, border='preserve')
+  want = c_oracle.COracle(total).run(inputs)
+  assert np.array_equal(got['v'], want['v'])
+
+
 C5 = ('jacobi2d.soda', (8192, 8192), 1000, (12, 4), 3)
 C4 = ('heat3d.soda', (512, 512, 512), 50, (2,), 2)
 

@@ -2,7 +2,8 @@
 """One-off scan of random programs beyond the seeds the test suite holds: the
 generic generator (tests/fuzz.py program) and the window generator
 (window_program), GPU kernels (auto and direct) against the C oracle, bit for
-bit.  Usage: python tools/fuzz_scan.py window|generic|rich FIRST LAST"""
+bit; `group`: the same programs cut into virtual slabs (group_scan).
+Usage: python tools/fuzz_scan.py window|generic|rich|group FIRST LAST"""
 import os
 import sys
 import time
@@ -67,5 +68,84 @@ def main():
   return 1 if failed else 0
 
 
+def group_scan(first, last):
+  """Random iterable programs on 2-6 virtual slabs of the one GPU (random
+  exchange interval, fusion depth, enqueueing threads, `border: preserve`)
+  through soda_hip_group_* against the C oracle, bit for bit."""
+  import fuzz
+  from oracle import c_oracle
+  from soda_amd import core, runtime, util
+  from soda_amd.codegen.hip import lower
+  ran = failed = skipped = 0
+  t0 = time.time()
+  for seed in range(first, last):
+    rng = np.random.default_rng(seed + 31000)
+    kind = ['plain', 'window', 'rich'][int(rng.integers(3))]
+    text, dim, _ = (fuzz.window_program(seed) if kind == 'window' else
+                    fuzz.program(seed, rich=kind == 'rich'))
+    if dim == 1:
+      continue
+    iterate = int(rng.integers(1, 8))
+    border = 'preserve' if rng.random() < 0.3 else None
+    try:
+      stencil = core.from_text(text, iterate=iterate,
+                               **({'border': border} if border else {}))
+      if border:
+        stencil.check_preserve()
+    except util.SodaError:
+      continue
+    extent = ((int(rng.choice([64, 130, 258, 300])), int(rng.integers(150, 420)))
+              if dim == 2 else
+              (int(rng.choice([40, 64, 130])), int(rng.integers(10, 24)),
+               int(rng.integers(60, 130))))
+    lo, hi = stencil.valid_box(extent)
+    if not border and not all(h > l for l, h in zip(lo, hi)):
+      continue
+    slabs = int(rng.integers(2, 7))
+    every = int(rng.integers(0, iterate + 1))
+    fuse = [(), (2,), (3, 2), (4,)][int(rng.integers(4))]
+    threads = bool(rng.random() < 0.3)
+    overlap = bool(rng.random() < 0.8)
+    ins = fuzz.inputs_for(stencil, extent, seed)
+    want = c_oracle.COracle(stencil, openmp=False).run(ins)
+    what = ('seed %d %s dim %d iterate %d border %s extent %s slabs %d every %d '
+            'fuse %s threads %s overlap %s' %
+            (seed, kind, dim, iterate, border, extent, slabs, every, fuse,
+             threads, overlap))
+    try:
+      with runtime.Group(stencil, extent, [0] * slabs,
+                         lower.LowerOptions(fuse=fuse), exchange_every=every,
+                         overlap=overlap, threads=threads) as group:
+        got = group.run_host(ins)
+    except util.SodaError as e:
+      if 'thinner' in str(e) or 'ghost' in str(e):
+        skipped += 1
+        continue
+      failed += 1
+      print('%s: %s: %s\n%s' % (what, type(e).__name__, str(e)[:300], text),
+            flush=True)
+      continue
+    ran += 1
+    for o in stencil.output_names:
+      if border:
+        g, w = got[o], want[o]
+      else:
+        lo, hi = stencil.valid_box(extent, o)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+        g, w = got[o][idx], want[o][idx]
+      if not np.array_equal(g, w, equal_nan=True):
+        failed += 1
+        print('%s output %s: %d cells differ\n%s' %
+              (what, o, int((g != w).sum()), text), flush=True)
+    if ran % 25 == 0:
+      print('... %d groups, %d failures, %d skipped, %.0f s' %
+            (ran, failed, skipped, time.time() - t0), flush=True)
+  print('group seeds [%d, %d): %d groups run, %d skipped (slabs thinner than '
+        'their ghosts), %d failures' % (first, last, ran, skipped, failed))
+  return 1 if failed else 0
+
+
 if __name__ == '__main__':
+  if sys.argv[1] == 'group':
+    sys.exit(group_scan(int(sys.argv[2]), int(sys.argv[3])))
   sys.exit(main())
