@@ -22,7 +22,10 @@
 // the copy into them may start.  State ping-pongs between two arrays per
 // tensor; that a neighbour has finished reading an array before its owner
 // overwrites it follows from the chain  copy -> neighbour's B(first) ->
-// neighbour's B(last) -> S -> my next copy -> my B(first) -> my last pass.
+// neighbour's B(last) -> S -> my next copy -> my B(first) -> my last pass --
+// where I fetch from that neighbour.  With a one-sided reach I do not, so
+// `main` also waits, at the head of interval j, for G(j - 1) of every
+// neighbour that fetched from me (enqueue_interval).
 #include "soda_internal.h"
 
 #include <atomic>
