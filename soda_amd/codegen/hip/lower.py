@@ -54,7 +54,6 @@ from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_FUSE_PRESERVE,  # noqa:
 # whole module
 # ---------------------------------------------------------------------------
 
-DEFAULT_COUNTED_WAITS = False
 MAX_TENSORS = 16       # SODA_HIP_MAX_TENSORS (include/soda_hip.h)
 # integer sums along the streamed dimension as sliding sums in the marching
 # kernels (march.py `slide`) instead of power-of-two chains (SODA_HIP_SLIDE=0/1)
@@ -80,7 +79,7 @@ class LowerOptions:
                occupancy: int = 0, buffer_ops: bool = True,
                pipe: Optional[int] = None, pipe_rows: int = 2,
                reg_budget: Optional[int] = None,
-               counted_waits: Optional[bool] = None, stamps: bool = False,
+               stamps: bool = False,
                peel=None, align_lanes: Optional[int] = None,
                xshare: Optional[bool] = None,
                row_cells: Optional[int] = None,
@@ -122,12 +121,6 @@ class LowerOptions:
     # runtime.select_peel choose per kernel from the compiled register counts
     # (lower() itself treats None as -1)
     self.peel = peel
-    # None: the default (DEFAULT_COUNTED_WAITS; SODA_HIP_COUNTED_WAITS=0/1
-    # overrides it for A/B runs of the whole test suite)
-    if counted_waits is None:
-      env = os.environ.get('SODA_HIP_COUNTED_WAITS')
-      counted_waits = DEFAULT_COUNTED_WAITS if env is None else env == '1'
-    self.counted_waits = counted_waits
     # estimated VGPRs a marching shape may need before the ladder in lower()
     # moves on to a leaner one (None: REG_BUDGET)
     self.reg_budget = reg_budget
@@ -165,7 +158,7 @@ class LowerOptions:
                        self.edge_loads, self.tile_rows, self.warm_guards,
                        self.interleave, self.lane_shift, self.min_waves,
                        self.occupancy, self.buffer_ops, self.pipe,
-                       self.pipe_rows, self.reg_budget, self.counted_waits,
+                       self.pipe_rows, self.reg_budget,
                        self.stamps, self.peel, self.align_lanes, self.xshare,
                        self.row_cells, self.windows, self.inline)
     if out.prefetch is None and dim == 3:
@@ -336,7 +329,7 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
                         opts.interleave,
                         shift, opts.min_waves, opts.occupancy,
                         opts.buffer_ops,
-                        pipe_for(t), opts.pipe_rows, opts.counted_waits,
+                        pipe_for(t), opts.pipe_rows,
                         opts.stamps, peel_for(t),
                         opts.align_lanes if opts.align_lanes is not None else
                         (max(1, 64 // (vec * out_bytes)) if opts.nt_store

@@ -94,7 +94,7 @@ class MarchConfig:
                interleave: bool = False, lane_shift: str = 'dpp',
                min_waves: int = 0, occupancy: int = 0,
                buffer_ops: bool = True, pipe: int = 1, pipe_rows: int = 4,
-               counted_waits: bool = False, stamps: bool = False,
+               stamps: bool = False,
                peel: int = -1, align_lanes: int = 1, xshare: int = 0,
                xwindow: bool = True, slide: bool = True):
     # integer window reductions along dimension 0 evaluated for all cells of
@@ -131,10 +131,6 @@ class MarchConfig:
     # diagnostics: every wave records s_memtime at entry and exit and where it
     # ran (tools/timeline.py)
     self.stamps = stamps
-    # input rows loaded by inline-asm loads the compiler does not count, with
-    # one hand-counted `s_waitcnt vmcnt(N)` per row step (soda_rt.h): hipcc's
-    # own waits drain the whole prefetch queue once per trip of the loop
-    self.counted_waits = counted_waits and buffer_ops
     # row steps per barrier of a stage-pipelined block (power of two): the
     # waves synchronise once per `pipe_rows` rows through a ring of twice
     # that many slots
@@ -206,7 +202,6 @@ class MarchConfig:
                     '_noshift' if self.lane_shift == 'none' else '') + (
                         '_mw%d' % self.min_waves if self.min_waves else '') + (
                             '_occ%d' % self.occupancy if self.occupancy else '') + (
-                                '_cw' if self.counted_waits else
                                 '_buf' if self.buffer_ops else '') + (
                                     '_pipe%dx%d' % (self.pipe, self.pipe_rows)
                                     if self.pipe > 1 else '') + (
@@ -420,7 +415,7 @@ class _MarchKernel:
     if self.xs:
       self.edge = (0, 0)    # the inputs' halo cells travel through LDS as well
       if self.W > 1 or self.cfg.lane_shift != 'dpp' or not self.cfg.buffer_ops \
-          or self.cfg.counted_waits or self.cfg.waves_x * self.cfg.waves_y != 1:
+          or self.cfg.waves_x * self.cfg.waves_y != 1:
         raise util.SemanticError(
             'march: x-halo sharing needs DPP shifts, buffer addressing and '
             'one wave per strip')
@@ -592,37 +587,6 @@ class _MarchKernel:
       return False
     return self.m_lo + self.lead + step >= lo + n.delay
 
-  # -- counted waits: raw register groups of the asm loads ---------------------
-  @staticmethod
-  def _groups(nbytes: int) -> List[int]:
-    """Bytes of each load instruction that fetches a `nbytes` fragment."""
-    return [16] * (nbytes // 16) if nbytes % 16 == 0 else [nbytes]
-
-  _RAW_TYPE = {16: 'soda_u32x4', 8: 'soda_u32x2', 4: 'unsigned', 2: 'unsigned',
-               1: 'unsigned'}
-
-  def raw_groups(self, n: _Node, slot: int, j: int):
-    """(variable, bytes, byte offset in the fragment, edge index or None) of
-    every load instruction that fills row j of `slot` of input `n`."""
-    es = self.esz[n.key[1]]
-    out = []
-    for g, nb in enumerate(self._groups(self.V * es)):
-      out.append(('%s_s%d_r%d_q%d' % (n.var, slot, j, g), nb, 16 * g, None))
-    for i in range(self.n_edge):
-      out.append(('%s_s%d_r%d_qe%d' % (n.var, slot, j, i), es, 0, i))
-    return out
-
-  def vmem_per_tick(self, wv: int):
-    """(load, store) instructions wave `wv` issues per row step."""
-    nl = ns = 0
-    if wv == 0:
-      for n in self.inputs.values():
-        nl += len(self.rows_of(n)) * len(self.raw_groups(n, 0, 0))
-    for o, n in self.outputs.items():
-      if n.owner == wv:
-        ns += len(self.store_rows(n)) * len(self._groups(self.V * self.esz[o]))
-    return nl, ns
-
   def store_rows(self, n: _Node):
     return range(max(n.rmargin[0], self.rhalo_lo),
                  self.rows_in - max(n.rmargin[1], self.rhalo_hi))
@@ -735,7 +699,6 @@ class _MarchKernel:
 
   def _emit_addressing(self) -> None:
     self.buf = self.cfg.buffer_ops
-    self.cw = self.cfg.counted_waits and self.buf
     table0 = self.st.symbol_table
     self.esz = {nme: table0[nme].size_in_bytes for nme in list(self.inputs) + list(self.outputs)}
     self.n_edge = max(self.edge)
@@ -939,9 +902,6 @@ class _MarchKernel:
               self.w('  %s %s_s%d_r%d_e[%d];' % (n.ctype, n.var, s, j, self.n_edge))
               self.w('  soda_zero_frag<%s, %d>(%s_s%d_r%d_e);' %
                 (n.ctype, self.n_edge, n.var, s, j))
-            if n.is_input and self.cw:
-              for var, nb, _, _ in self.raw_groups(n, s, j):
-                self.w('  %s %s = {};' % (self._RAW_TYPE[nb], var))
           if n.xs:
             # halo cells of the plane in slot s: lane r / 32 + r holds row r's
             # left / right neighbour cell
@@ -955,11 +915,11 @@ class _MarchKernel:
       VGPRs)."""
       self.w('      const int t = %s;' % t_expr)
       self.w('      const bool plane_ok = t >= 0 && t < in_end;')
-      if pin and self.buf and not self.cw:
+      if pin and self.buf:
         for es in sorted({self.esz[nme] for nme in self.inputs}):
           self.w('      unsigned xb%dp = xb%d; asm volatile("" : "+v"(xb%dp));'
                  % (es, es, es))
-      pinned = 'p' if pin and self.buf and not self.cw else ''
+      pinned = 'p' if pin and self.buf else ''
       if self.buf:
         in_es = sorted({self.esz[nme] for nme in self.inputs})
         for es in in_es:
@@ -977,17 +937,7 @@ class _MarchKernel:
                      (es, j, es, es, j))
       for nme, n in self.inputs.items():
         s = self.slot_of(n, k, 0)
-        for j in (self.rows_of(n) if self.cw else []):
-          es = self.esz[nme]
-          ro = 'ro%d' % es if self.dim == 2 else 'ro%d_%d' % (es, j)
-          for var, nb, boff, ei in self.raw_groups(n, s, j):
-            if ei is None:
-              self.w('      soda_asm_buf_load<%d, %s>(%s, r_%s, %s + xb%d + %du);'
-                     % (nb, self.nt_l, var, nme, ro, es, boff))
-            else:
-              self.w('      soda_asm_buf_load<%d, false>(%s, r_%s, %s + exb%d_%d);'
-                     % (nb, var, nme, ro, ei, es))
-        for j in (self.rows_of(n) if self.buf and not self.cw else []):
+        for j in (self.rows_of(n) if self.buf else []):
           es = self.esz[nme]
           ro = 'ro%d' % es if self.dim == 2 else 'ro%d_%d' % (es, j)
           reg = '%s_s%d_r%d' % (n.var, s, j)
@@ -1026,15 +976,9 @@ class _MarchKernel:
     # load-only prologue whose slot phases continue into tick 0 of the loop.
     self.w('  int tau = m_begin + (%d);' % (self.m_lo + self.lead))
     if wv == 0:
-      if self.cw:
-        # the descriptors come out of scalar/readfirstlane arithmetic; asm loads
-        # get no hazard padding from the compiler (cdna_hip_programming.md 5.7)
-        self.w('  asm volatile("s_nop 4");')
       for i in range(self.lead):
         self.w('    {  // prologue: loads of plane tau - %d' % (self.lead - i))
         self.emit_loads((i - self.lead) % self.U, 'tau - %d' % (self.lead - i))
-        if self.cw:
-          self._emit_dummy_stores(wv)
         self.w('    }')
     self.w('  const int tau_end = m_end + %d;' % self.max_delay)
     if self.peeled:
@@ -1060,65 +1004,7 @@ class _MarchKernel:
       self._emit_tick(wv, k)
     self.w('  }')
     if self.W > 1:
-      if self.cw and wv == 0:
-        # the rows prefetched past the chunk (out of range: dropped by the
-        # memory pipeline) must have retired before the registers are reused
-        # by code the compiler places behind this branch
-        self.w('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
       self.w('  }')
-
-  def _emit_dummy_stores(self, wv: int, only: Optional[_Node] = None,
-                         salt: int = 0) -> None:
-    """Counted waits: a load-only prologue step still issues the stores of a
-    row step, out of range (the memory pipeline drops them), so that every step
-    of the wave is the same sequence of vector-memory instructions and ONE
-    constant serves every wait."""
-    # every dummy store gets an out-of-range offset of its own: identical
-    # stores would be merged by the compiler's dead-store elimination and the
-    # hand count would be off (found by tools/waitcheck.py on heat3d)
-    i = 64 * salt
-    for o, n in self.outputs.items():
-      if n.owner != wv or (only is not None and n is not only):
-        continue
-      es = self.esz[o]
-      for j in self.store_rows(n):
-        self.w('      soda_buf_store_frag<%s, %d, %s>(w_%s, SODA_OOB_ROW + sxb%d + '
-               '%du, %s_s0_r%d);' % (n.ctype, self.V, self.nt_s, o, es,
-                                     4096 * i, n.var, j))
-        i += 1
-
-  def _emit_wait(self, wv: int, k: int) -> None:
-    """Counted waits: the input rows loaded PF steps ago are the youngest any
-    stage reads in this step.  Loads and stores retire in issue order, and every
-    step issues `nl` loads then `ns` stores, so all but the PF * (nl + ns)
-    youngest instructions must have completed."""
-    nl, ns = self.vmem_per_tick(wv)
-    count = min(63, self.PF * (nl + ns))      # vmcnt is a 6-bit counter
-    groups = []
-    unpack = []
-    for nme, n in self.inputs.items():
-      slot = self.slot_of(n, k, self.PF)
-      for j in self.rows_of(n):
-        typed = '%s_s%d_r%d' % (n.var, slot, j)
-        for g, (var, nb, boff, ei) in enumerate(self.raw_groups(n, slot, j)):
-          groups.append(var)
-          if ei is None:
-            unpack.append('      soda_unpack_frag<%s, %d>(%s, %s, %d);' %
-                          (n.ctype, self.V, typed, var, g))
-          else:
-            unpack.append('      { %s e1[1]; soda_unpack_frag<%s, 1>(e1, %s); '
-                          '%s_e[%d] = e1[0]; }' % (n.ctype, n.ctype, var, typed,
-                                                   ei))
-    first = True
-    while groups:
-      part, groups = groups[:4], groups[4:]
-      if first:
-        self.w('      SODA_WAIT_%d(%d, %s);' % (len(part), count,
-                                                ', '.join(part)))
-        first = False
-      else:
-        self.w('      SODA_TIE_%d(%s);' % (len(part), ', '.join(part)))
-    self.L.extend(unpack)
 
   def _emit_tick(self, wv: int, k: int, step: Optional[int] = None) -> None:
     """One row step at slot phase k; `step` = its number within the peeled
@@ -1130,8 +1016,6 @@ class _MarchKernel:
       self.w('      soda_pipe_barrier();')
     if wv == 0:
       self.emit_loads(k, 'tau + %d' % at, pin=step is not None)
-      if self.cw:
-        self._emit_wait(wv, k)
     else:
       self.w('      const int t = tau + %d;' % at)
     for n in self.nodes:
@@ -1166,8 +1050,6 @@ class _MarchKernel:
     for n in self.nodes:
       if n.stage is not None and n.owner == wv:
         if step is not None and not self.stage_needed(n, step):
-          if self.cw and n.store_slot is not None:
-            self._emit_dummy_stores(wv, only=n, salt=step + 1)
           continue
         first = step is not None and (step == 0 or
                                       not self.stage_needed(n, step - 1))

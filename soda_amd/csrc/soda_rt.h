@@ -460,94 +460,6 @@ SODA_DEV void soda_buf_store_frag(soda_rsrc_t r, unsigned off,
   }
 }
 
-// ---- loads the compiler does not count (exact, hand-counted waits) ----------
-// hipcc's s_waitcnt insertion is exact inside one basic block, but at the head
-// of the marching loop (values loaded in one trip, used in the next) it falls
-// back to `s_waitcnt vmcnt(0)`: once per trip every wave drained its whole
-// prefetch queue AND its stores (seen in the ISA of every marching kernel:
-// T=1 with 8 rows in flight, T=12 with 2).  These loads are inline asm, which
-// the compiler neither counts nor waits for; the generator knows the order of
-// all vector-memory instructions of a row step and emits the one wait a step
-// needs itself, `s_waitcnt vmcnt(N)` with N = the number of loads and stores
-// issued after the loads being waited for (they retire in issue order).
-//
-// Rules that make this safe (cdna_hip_programming.md 5.7, form ii):
-//  * a load's destination is a raw 16-byte register group that nothing reads
-//    until it has passed through soda_wait_loads(), which names it "+v" --
-//    consumers cannot be scheduled above the wait;
-//  * the asm statements are volatile with a "memory" clobber: the compiler
-//    keeps them, the stores (builtins) and each other in program order, so
-//    the hand count is the issue order;
-//  * tools/waitcheck.py replays the compiled ISA and fails if any instruction
-//    touches a register group while its load is still in flight (a copy the
-//    register allocator might insert would read stale data).
-// raw register groups: 16 / 8 / <= 4 bytes per lane
-#define SODA_ASM_LOAD(op, dst, r, off, nt)                                 \
-  do {                                                                     \
-    if constexpr (nt)                                                      \
-      asm volatile(op " %0, %1, %2, 0 offen nt"                            \
-                   : "=v"(dst) : "v"(off), "s"(r) : "memory");             \
-    else                                                                   \
-      asm volatile(op " %0, %1, %2, 0 offen"                               \
-                   : "=v"(dst) : "v"(off), "s"(r) : "memory");             \
-  } while (0)
-
-template <int kBytes, bool kNonTemporal>
-SODA_DEV void soda_asm_buf_load(soda_u32x4& dst, soda_rsrc_t r, unsigned off) {
-  static_assert(kBytes == 16, "group size");
-  SODA_ASM_LOAD("buffer_load_dwordx4", dst, r, off, kNonTemporal);
-}
-template <int kBytes, bool kNonTemporal>
-SODA_DEV void soda_asm_buf_load(soda_u32x2& dst, soda_rsrc_t r, unsigned off) {
-  static_assert(kBytes == 8, "group size");
-  SODA_ASM_LOAD("buffer_load_dwordx2", dst, r, off, kNonTemporal);
-}
-template <int kBytes, bool kNonTemporal>
-SODA_DEV void soda_asm_buf_load(unsigned& dst, soda_rsrc_t r, unsigned off) {
-  static_assert(kBytes == 4 || kBytes == 2 || kBytes == 1, "group size");
-  if constexpr (kBytes == 4)
-    SODA_ASM_LOAD("buffer_load_dword", dst, r, off, kNonTemporal);
-  else if constexpr (kBytes == 2)
-    SODA_ASM_LOAD("buffer_load_ushort", dst, r, off, kNonTemporal);
-  else
-    SODA_ASM_LOAD("buffer_load_ubyte", dst, r, off, kNonTemporal);
-}
-
-// raw register group -> (part of a) typed fragment: register renaming, legal
-// only after the group has passed through a wait
-template <class T, int V, class R>
-SODA_DEV void soda_unpack_frag(T (&dst)[V], const R& raw, int group = 0) {
-  constexpr int kBytes = V * (int)sizeof(T);
-  if constexpr (kBytes >= 16) {
-    __builtin_memcpy((char*)dst + 16 * group, &raw, 16);
-  } else if constexpr (kBytes >= 4) {
-    __builtin_memcpy(dst, &raw, kBytes);
-  } else if constexpr (kBytes == 2) {
-    const unsigned short t = (unsigned short)raw;
-    __builtin_memcpy(dst, &t, 2);
-  } else {
-    const unsigned char t = (unsigned char)raw;
-    __builtin_memcpy(dst, &t, 1);
-  }
-}
-
-// `s_waitcnt vmcnt(N)` tied to the register groups it guards
-#define SODA_WAIT_1(n, a) \
-  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a) :: "memory")
-#define SODA_WAIT_2(n, a, b) \
-  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b) :: "memory")
-#define SODA_WAIT_3(n, a, b, c) \
-  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c) :: "memory")
-#define SODA_WAIT_4(n, a, b, c, d)                                         \
-  asm volatile("s_waitcnt vmcnt(" #n ")"                                   \
-               : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
-// more groups: further statements that only tie registers (no instruction)
-#define SODA_TIE_1(a) asm volatile("" : "+v"(a) :: "memory")
-#define SODA_TIE_2(a, b) asm volatile("" : "+v"(a), "+v"(b) :: "memory")
-#define SODA_TIE_3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory")
-#define SODA_TIE_4(a, b, c, d) \
-  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
-
 // ---- stage-pipelined blocks ------------------------------------------------
 // One barrier per row step: every LDS access this wave has issued has
 // completed (lgkmcnt(0)) before any wave of the block starts the next step.

@@ -362,38 +362,6 @@ def test_print_code_accepts_a_foreign_stencil_object(tmp_path):
   assert open(ref).read() == text
 
 
-def test_counted_waits_are_exact_in_the_compiled_code(built):
-  """`counted_waits`: input rows loaded by inline-asm loads hipcc does not
-  count, one hand-counted `s_waitcnt vmcnt(N)` per row step.  tools/waitcheck.py
-  replays the COMPILED ISA with the hardware's retire-in-issue-order rule: no
-  instruction may touch a register whose load is in flight, and every wait in
-  the loop must leave the prefetched rows in flight (N > 0) -- whereas the
-  compiler's own waits drain the queue (`vmcnt(0)`) once per trip."""
-  import sys
-  sys.path.insert(0, os.path.join(ROOT, 'tools'))
-  import waitcheck
-  from soda_amd import runtime
-  from soda_amd.codegen.hip import lower
-  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=8)
-  seen = {}
-  for cw in (True, False):
-    mod = lower.lower(stencil, lower.LowerOptions(fuse=(4,), vec=4, peel=0,
-                                                  counted_waits=cw))
-    asm = waitcheck.compile_to_asm(mod.source, runtime.COMPILE_OPTIONS)
-    for name, lines in waitcheck.kernels_of(asm).items():
-      res = waitcheck.check(lines)
-      assert not res['scratch']
-      seen[(cw, 'T4' in name)] = res
-      if cw:
-        assert res['violations'] == [], res['violations'][:3]
-        assert res['loop_waits'] and min(res['loop_waits']) > 0
-        assert res['load_to_wait_instructions'][0] > 50
-  # T = 4, prefetch 4, one load and one store per step: all but 8 may be out
-  assert set(seen[(True, True)]['loop_waits']) == {8}
-  # the compiler-counted build drains at the head of every trip
-  assert min(seen[(False, True)]['loop_waits']) == 0
-
-
 def test_row_covering_blocks_in_the_plan(built):
   """3-D fused kernels built for a known row length: the block's waves cover
   the row (x-halos through LDS), the descriptor says so, and the library --

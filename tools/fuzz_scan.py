@@ -3,7 +3,8 @@
 generic generator (tests/fuzz.py program) and the window generator
 (window_program), GPU kernels (auto and direct) against the C oracle, bit for
 bit; `group`: the same programs cut into virtual slabs (group_scan).
-Usage: python tools/fuzz_scan.py window|generic|rich|group FIRST LAST"""
+`options`: random backend knobs on larger grids (options_scan).
+Usage: python tools/fuzz_scan.py window|generic|rich|group|options FIRST LAST"""
 import os
 import sys
 import time
@@ -147,7 +148,84 @@ def group_scan(first, last):
   return 1 if failed else 0
 
 
+def options_scan(first, last):
+  """Random programs on grids of several strips and chunks with random backend
+  knobs: chunk length (the launch-time tuner may pick any), peeled warm-up,
+  fusion depth, prefetch depth, lane-shift flavour, cells per lane, blocks that
+  share rows, pipelined waves, the rewrites on / off."""
+  import fuzz
+  from oracle import c_oracle
+  from soda_amd import core, runtime, util
+  from soda_amd.codegen.hip import lower
+  ran = failed = refused = 0
+  t0 = time.time()
+  for seed in range(first, last):
+    rng = np.random.default_rng(seed + 47000)
+    kind = ['plain', 'window', 'window', 'rich'][int(rng.integers(4))]
+    text, dim, iterate = (fuzz.window_program(seed) if kind == 'window' else
+                          fuzz.program(seed, rich=kind == 'rich'))
+    if dim == 1:
+      continue
+    try:
+      stencil = core.from_text(text)
+    except util.SodaError:
+      continue
+    extent = ((int(rng.choice([300, 520, 777, 1100])), int(rng.integers(60, 260)))
+              if dim == 2 else
+              (int(rng.choice([64, 130, 300])), int(rng.integers(12, 40)),
+               int(rng.integers(20, 70))))
+    lo, hi = stencil.valid_box(extent)
+    if not all(h > l for l, h in zip(lo, hi)):
+      continue
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    kw = dict(fuse=pick([(), (2,), (3,), (3, 2)]),
+              chunk_rows=pick([None, None, 3, 5, 9, 16, 33]),
+              peel=pick([None, None, 0, 1, -1]),
+              prefetch=pick([None, None, 1, 2, 4]),
+              lane_shift=pick([None, None, None, 'dpp', 'mixh', 'swzh',
+                               'bperm']) if dim == 2 else None,
+              windows=pick([None, None, False]),
+              inline=pick([None, None, False]),
+              xshare=pick([None, None, None, True]),
+              nt_store=pick([None, None, True, False]),
+              tile_rows=pick([None, None, 2, 4, 6]) if dim == 3 else None)
+    if rng.random() < 0.15 and dim == 2 and kw['fuse'] in ((2,), ):
+      kw['pipe'] = 2
+    if rng.random() < 0.15:
+      kw['waves_y'] = 2
+    ins = fuzz.inputs_for(stencil, extent, seed)
+    want = c_oracle.COracle(stencil, openmp=False).run(ins)
+    what = 'seed %d %s extent %s %s' % (seed, kind, extent, kw)
+    try:
+      with runtime.Program(stencil, lower.LowerOptions(**kw),
+                           extent=extent) as prog:
+        got = prog.run(ins)
+    except (util.SodaError, ValueError) as e:
+      refused += 1        # a knob the program / shape does not admit
+      if not any(w in str(e) for w in ('cannot', 'need', 'fit', 'must',
+                                       'support', 'not ', 'only')):
+        print('%s: %s: %s' % (what, type(e).__name__, str(e)[:300]), flush=True)
+      continue
+    ran += 1
+    for o in stencil.output_names:
+      lo, hi = stencil.valid_box(extent, o)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      g, w = got[o][idx], want[o][idx]
+      if not np.array_equal(g, w, equal_nan=True):
+        failed += 1
+        print('%s output %s: %d cells differ\n%s' %
+              (what, o, int((g != w).sum()), text), flush=True)
+    if ran % 25 == 0:
+      print('... %d programs, %d failures, %d refused, %.0f s' %
+            (ran, failed, refused, time.time() - t0), flush=True)
+  print('options seeds [%d, %d): %d programs run, %d refused, %d failures' %
+        (first, last, ran, refused, failed))
+  return 1 if failed else 0
+
+
 if __name__ == '__main__':
+  if sys.argv[1] == 'options':
+    sys.exit(options_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'group':
     sys.exit(group_scan(int(sys.argv[2]), int(sys.argv[3])))
   sys.exit(main())

@@ -24,7 +24,6 @@ def main():
   ap.add_argument('--nt-load', type=int, nargs='+', default=[1])
   ap.add_argument('--nt-store', type=int, nargs='+', default=[0])
   ap.add_argument('--tile-rows', type=int, nargs='+', default=[6])
-  ap.add_argument('--cw', type=int, nargs='+', default=[0])
   ap.add_argument('--peel', type=int, nargs='+', default=[-2])
   ap.add_argument('--mw', type=int, nargs='+', default=[0])
   ap.add_argument('--reg-budget', type=int, default=None)
@@ -32,9 +31,9 @@ def main():
   args = ap.parse_args()
   from soda_amd import core, runtime
   from soda_amd.codegen.hip import lower
-  for fuse, pf, vec, shift, pipe, prow, ntl, nts, trows, cw, peel, mw in itertools.product(
+  for fuse, pf, vec, shift, pipe, prow, ntl, nts, trows, peel, mw in itertools.product(
       args.fuse, args.prefetch, args.vec, args.shift, args.pipe,
-      args.pipe_rows, args.nt_load, args.nt_store, args.tile_rows, args.cw,
+      args.pipe_rows, args.nt_load, args.nt_store, args.tile_rows,
       args.peel, args.mw):
     st = core.from_file(args.soda, iterate=fuse * args.launches)
     opts = lower.LowerOptions(fuse=(fuse,) if fuse > 1 else (), prefetch=pf,
@@ -42,7 +41,7 @@ def main():
                               pipe_rows=prow, nt_load=bool(ntl),
                               nt_store=bool(nts), xcd_swizzle=True,
                               tile_rows=trows, waves_x=1, waves_y=1,
-                              counted_waits=bool(cw), peel=(None if peel == -2 else peel),
+                              peel=(None if peel == -2 else peel),
                               min_waves=mw, reg_budget=args.reg_budget)
     try:
       opts = runtime.resolve_options(st, opts, args.extent)

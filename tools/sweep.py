@@ -35,7 +35,6 @@ def main():
   ap.add_argument('--buf', type=int, nargs='+', default=[1])
   ap.add_argument('--pipe', type=int, nargs='+', default=[1])
   ap.add_argument('--pipe-rows', type=int, nargs='+', default=[4])
-  ap.add_argument("--cw", type=int, nargs="+", default=[0])
   ap.add_argument("--peel", type=int, nargs="+", default=[-2])
   ap.add_argument('--reg-budget', type=int, default=None)
   ap.add_argument('--rounds', type=int, default=3)
@@ -51,17 +50,17 @@ def main():
   shape = tuple(args.extent[::-1])
   configs = list(itertools.product(args.fuse, args.chunk, args.prefetch,
                                    args.waves, args.nt_store, args.nt_load,
-                                   args.xcd, args.vec, args.tile_rows, args.edge, args.wg, args.il, args.shift, args.mw, args.occ, args.buf, args.pipe, args.pipe_rows, args.cw, args.peel))
+                                   args.xcd, args.vec, args.tile_rows, args.edge, args.wg, args.il, args.shift, args.mw, args.occ, args.buf, args.pipe, args.pipe_rows, args.peel))
   progs = []
   stream = torch.cuda.current_stream().cuda_stream
-  for fuse, chunk, pf, waves, nts, ntl, xcd, vec, trows, edge, wg, il, shift, mw, occ, buf, pipe, prow, cw, peel in configs:
+  for fuse, chunk, pf, waves, nts, ntl, xcd, vec, trows, edge, wg, il, shift, mw, occ, buf, pipe, prow, peel in configs:
     st = core.from_file(args.soda, iterate=fuse * args.launches)
     wx, wy = map(int, waves.split('x'))
     opts = lower.LowerOptions(strategy=args.strategy, fuse=(fuse,) if fuse > 1 else (), chunk_rows=chunk if chunk > 0 else None,
                               prefetch=pf, waves_x=wx, waves_y=wy,
                               nt_store=bool(nts), nt_load=bool(ntl),
                               xcd_swizzle=bool(xcd), vec=vec if vec > 0 else None,
-                              tile_rows=trows, edge_loads=bool(edge), warm_guards=bool(wg), interleave=bool(il), lane_shift=shift, min_waves=mw, occupancy=occ, buffer_ops=bool(buf), pipe=pipe, pipe_rows=prow, reg_budget=args.reg_budget, counted_waits=bool(cw), peel=(None if peel == -2 else peel))
+                              tile_rows=trows, edge_loads=bool(edge), warm_guards=bool(wg), interleave=bool(il), lane_shift=shift, min_waves=mw, occupancy=occ, buffer_ops=bool(buf), pipe=pipe, pipe_rows=prow, reg_budget=args.reg_budget, peel=(None if peel == -2 else peel))
     try:
       progs.append((runtime.Program(st, opts, extent=args.extent), st, fuse))
     except Exception as e:  # noqa
@@ -106,7 +105,7 @@ def main():
     best = min(times[i]); med = sorted(times[i])[len(times[i]) // 2]
     fuse = cfg[0]
     rows.append(dict(fuse=fuse, chunk=cfg[1], prefetch=cfg[2], waves=cfg[3],
-                     nt_store=cfg[4], nt_load=cfg[5], xcd=cfg[6], vec=cfg[7], tile_rows=cfg[8], edge=cfg[9], wg=cfg[10], il=cfg[11], shift=cfg[12], mw=cfg[13], occ=cfg[14], buf=cfg[15], pipe=cfg[16], pipe_rows=cfg[17], cw=cfg[18], peel=cfg[19], ms_min=best,
+                     nt_store=cfg[4], nt_load=cfg[5], xcd=cfg[6], vec=cfg[7], tile_rows=cfg[8], edge=cfg[9], wg=cfg[10], il=cfg[11], shift=cfg[12], mw=cfg[13], occ=cfg[14], buf=cfg[15], pipe=cfg[16], pipe_rows=cfg[17], peel=cfg[18], ms_min=best,
                      ms_med=med, GBs=cells * bytes_cell / best / 1e6,
                      Gcell_iters=cells * fuse / best / 1e6,
                      kernel=progs[i][0].module.kernels[0].name))

@@ -34,7 +34,6 @@ def main():
   ap.add_argument('--pipe-rows', type=int, default=2)
   ap.add_argument('--shift', default='dpp')
   ap.add_argument('--vec', type=int, default=None)
-  ap.add_argument('--cw', type=int, default=0)
   ap.add_argument('--tag', default='')
   ap.add_argument('--out', default=None)
   args = ap.parse_args()
@@ -48,7 +47,7 @@ def main():
                             chunk_rows=args.chunk or None,
                             prefetch=args.prefetch, pipe=args.pipe,
                             pipe_rows=args.pipe_rows, lane_shift=args.shift,
-                            vec=args.vec, counted_waits=bool(args.cw),
+                            vec=args.vec, 
                             stamps=True)
   prog = runtime.Program(st, opts, extent=args.extent)
   shape = tuple(args.extent[::-1])
