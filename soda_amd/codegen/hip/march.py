@@ -1294,6 +1294,17 @@ class _MarchKernel:
       self.L.extend(self._lx_reads(n))
     self.L.extend(pre)
     self.L.extend(body)
+    if self.st.symbol_table[stage.name].size_in_bytes == 1:
+      # every cell of a one-byte tensor through a register of its own: left to
+      # itself the compiler packs the cells of a row into one register, and one
+      # of its instruction-selection combines on that form is wrong on gfx950
+      # (ROCm 7.2: a min whose operands come out of the packed register picked
+      # the wrong side in one cell of one unrolled step of a fused kernel --
+      # tools/fuzz_scan.py options, seed 613; exact with the pass that selects
+      # instructions run unoptimised)
+      for j in self.rows_of(n):
+        self.w('      soda_own_register<%s, %d>(%s_s%d_r%d);' %
+               (n.ctype, self.V, n.var, dst_slot, j))
     if id(n) in self.ldsx:
       lo, hi = self.ldsx[id(n)]
       reg = '%s_s%d_r0' % (n.var, dst_slot)

@@ -103,6 +103,14 @@ SODA_DEV int soda_opaque(int v) {
   return v;
 }
 
+// every element of a fragment in a 32-bit register of its own (no instruction:
+// the value passes through an empty asm the compiler cannot see through)
+template <class T, int V>
+SODA_DEV void soda_own_register(T (&v)[V]) {
+#pragma unroll
+  for (int e = 0; e < V; ++e) v[e] = (T)soda_opaque((int)v[e]);
+}
+
 template <class T, int kSize = sizeof(T), bool kFloat = __is_floating_point(T)>
 struct soda_lane_shift;
 

@@ -297,3 +297,32 @@ def test_gpu_matches_oracle_on_rich_programs(built, seed):
       assert np.array_equal(g, w, equal_nan=True), (
           'seed %d, %s (%s), output %s: %d cells differ\n%s' %
           (seed, strategy, kinds, o, int((g != w).sum()), text))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('opts', [dict(fuse=(2,)), dict(fuse=(2,), peel=-1),
+                                  dict(fuse=(3, 2), chunk_rows=9, waves_y=2)])
+def test_one_byte_locals_in_fused_kernels(built, opts):
+  """Program 613 of the plain generator on a grid of several strips and chunks:
+  a uint8 local between int16 / int32 tensors, two coupled outputs, iterate 3.
+  hipcc (ROCm 7.2) packs the four cells a lane holds of a one-byte tensor into
+  one register and mis-selects a min fed from it in ONE cell of ONE unrolled
+  step of the fused kernel (found by tools/fuzz_scan.py options; localised with
+  -opt-bisect-limit to instruction selection, tools/experiments/gen_bisect.py);
+  the kernels keep such cells in registers of their own (soda_own_register)."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  text, dim, _ = fuzz.program(613)
+  stencil = core.from_text(text)
+  extent = (1100, 207)
+  ins = fuzz.inputs_for(stencil, extent, 613)
+  want = c_oracle.COracle(stencil, openmp=False).run(ins)
+  with runtime.Program(stencil, lower.LowerOptions(**opts),
+                       extent=extent) as prog:
+    assert 'soda_own_register<uint8_t' in prog.module.source
+    got = prog.run(ins)
+  for o in stencil.output_names:
+    lo, hi = stencil.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(got[o][idx], want[o][idx]), o
