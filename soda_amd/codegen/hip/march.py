@@ -1197,6 +1197,7 @@ class _MarchKernel:
                         (n.var, dst_slot, j, e, n.ctype, acc, e))
             body.append('      %s[%d] -= %s;' % (acc, e, tap(0)))
       if slide_init == 'only':
+        self.L.extend(early)     # (shifts on the LDS pipe: nothing to hide behind here)
         self.L.extend(pre)
         self.L.extend(body)
         return

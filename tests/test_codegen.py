@@ -395,3 +395,26 @@ def test_row_covering_blocks_in_the_plan(built):
   # without the row length nothing is assumed
   plain = lower.lower(stencil, lower.LowerOptions(fuse=(2,), vec=4, peel=0))
   assert not any('_xs' in k.name for k in plain.kernels)
+
+
+@pytest.mark.parametrize('shift', ['bperm', 'swzh', 'mixh'])
+def test_sliding_sum_setup_with_lds_pipe_shifts_compiles(built, shift, tmp_path):
+  """A sliding sum whose taps sit a lane away (store index off-centre in x):
+  the accumulator's set-up in front of the loop needs the lane-shifted copies
+  too -- with shifts on the LDS pipe they are collected apart ("early") and
+  the set-up once forgot to emit them (found by tools/fuzz_scan.py options:
+  a loud compile error, never a wrong result)."""
+  import sys
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import fuzz
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  text, dim, _ = fuzz.window_program(712)
+  assert 'w0(1, -1) = in0(0, -9) + ' in text
+  stencil = core.from_text(text)
+  opts = runtime.resolve_options(
+      stencil, lower.LowerOptions(fuse=(3,), lane_shift=shift), (1100, 220),
+      probe=False)
+  mod = lower.lower(stencil, opts)
+  assert 'xa_t0_w0_r0' in mod.source
+  assert runtime.compile_source(mod.source, 'w.hip', cache_dir=str(tmp_path))
