@@ -148,7 +148,7 @@ def group_scan(first, last):
   return 1 if failed else 0
 
 
-def options_scan(first, last):
+def options_scan(first, last, only=None):
   """Random programs on grids of several strips and chunks with random backend
   knobs: chunk length (the launch-time tuner may pick any), peeled warm-up,
   fusion depth, prefetch depth, lane-shift flavour, cells per lane, blocks that
@@ -164,7 +164,7 @@ def options_scan(first, last):
     kind = ['plain', 'window', 'window', 'rich'][int(rng.integers(4))]
     text, dim, iterate = (fuzz.window_program(seed) if kind == 'window' else
                           fuzz.program(seed, rich=kind == 'rich'))
-    if dim == 1:
+    if dim == 1 or (only and only not in text):
       continue
     try:
       stencil = core.from_text(text)
@@ -178,7 +178,8 @@ def options_scan(first, last):
     if not all(h > l for l, h in zip(lo, hi)):
       continue
     pick = lambda xs: xs[int(rng.integers(len(xs)))]
-    kw = dict(fuse=pick([(), (2,), (3,), (3, 2)]),
+    kw = dict(strategy=pick(['auto', 'auto', 'auto', 'direct']) if only else 'auto',
+              fuse=pick([(), (2,), (3,), (3, 2)]),
               chunk_rows=pick([None, None, 3, 5, 9, 16, 33]),
               peel=pick([None, None, 0, 1, -1]),
               prefetch=pick([None, None, 1, 2, 4]),
@@ -224,8 +225,9 @@ def options_scan(first, last):
 
 
 if __name__ == '__main__':
-  if sys.argv[1] == 'options':
-    sys.exit(options_scan(int(sys.argv[2]), int(sys.argv[3])))
+  if sys.argv[1] == 'options':     # optional 4th argument: only programs containing it
+    sys.exit(options_scan(int(sys.argv[2]), int(sys.argv[3]),
+                          sys.argv[4] if len(sys.argv) > 4 else None))
   if sys.argv[1] == 'group':
     sys.exit(group_scan(int(sys.argv[2]), int(sys.argv[3])))
   sys.exit(main())
