@@ -140,14 +140,14 @@ def cpu_baseline(stencil, extent, target_seconds):
   return {
       'value': cells * iters / dt, 'unit': 'cells*iters/s', 'cores': cores,
       'kind': 'port',
-      'sample': '%s %s, iterate=%d (%.1f s), gcc -O2 -ffp-contract=off '
+      'sample': '%s %s, iterate=%d (%.1f s), gcc -O2 -ffp-contract=off -fwrapv '
                 '-fopenmp, %d threads' % (stencil.app_name,
                                           'x'.join(map(str, extent)), iters,
                                           dt, cores),
       'single_thread': {
           'value': cells * iters1 / dt1, 'unit': 'cells*iters/s', 'cores': 1,
           'kind': 'port',
-          'sample': '%s %s, iterate=%d (%.1f s), gcc -O2 -ffp-contract=off, '
+          'sample': '%s %s, iterate=%d (%.1f s), gcc -O2 -ffp-contract=off -fwrapv, '
                     '1 thread' % (stencil.app_name, 'x'.join(map(str, extent)),
                                   iters1, dt1),
       },

@@ -28,8 +28,16 @@ ARCH = 'gfx950'
 #   v_pk_add_f32/v_pk_mul_f32; on gfx950 those issue at half the rate of the
 #   scalar forms and need v_mov shuffles to line registers up (measured: same
 #   instruction count, ~25 % more cycles, 19 more VGPRs on jacobi2d T=8).
+# * `-fwrapv`: signed integer arithmetic wraps.  The reference's kernel is
+#   hardware (ap_int arithmetic: two's complement, no undefined behaviour);
+#   without the flag hipcc may and does compile an overflowing int32 product
+#   to something else than its wrapped value (tools/fuzz_scan.py, programs
+#   2184 / 3775: 10^4-10^5 cells away from gcc's result), and the two sides of
+#   a parity test would be comparing undefined behaviours.  The oracle's C is
+#   built with the same flag.  Cost: within run-to-run noise on every corpus
+#   program (profiles/r03_wrapv.json).
 COMPILE_OPTIONS = ('--offload-arch=%s' % ARCH, '-O3', '-ffp-contract=off',
-                   '-fno-slp-vectorize', '-std=c++17') + tuple(
+                   '-fno-slp-vectorize', '-fwrapv', '-std=c++17') + tuple(
                        os.environ.get('SODA_HIP_EXTRA_FLAGS', '').split())
 
 MAX_DIM = 4
