@@ -243,9 +243,22 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
              for s in stencil.ordered_stages)
   # the module's program from here on is a DERIVED one: same tensors the
   # caller sees (inputs, outputs, their windows and boxes), other locals
+  def same_boxes(other: core.Stencil) -> bool:
+    """A rewrite must leave the outputs' windows alone: they decide the valid
+    box and, under `border: preserve`, which cells an iteration computes.  A
+    tensor's window includes the tensor's own cell (core.iteration_boxes), so
+    folding a local that is STORED off-centre can widen what its consumer may
+    compute (`loc(0, -1) = in(1, 0); out(0, 0) = loc(0, -1)`: row 0 of `out`
+    needs row -1 of `loc`; folded, it needs nothing outside the grid -- found
+    by tools/fuzz_scan.py options, a preserved row computed instead)."""
+    mine, theirs = stencil.iteration_boxes(), other.iteration_boxes()
+    return all(mine[o] == theirs[o] for o in stencil.output_names)
+
   if opts.inline and opts.strategy != 'lds':
     from soda_amd.optimization import pointwise
-    stencil = pointwise.inline_pointwise(stencil)
+    folded = pointwise.inline_pointwise(stencil)
+    if same_boxes(folded):
+      stencil = folded
   if opts.windows and opts.strategy != 'lds':
     from soda_amd.optimization import windows
     # (the marching kernels reduce dimension-0 windows themselves, all cells
@@ -258,7 +271,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     derived = windows.decompose(stencil, skip=skip)
     # (the auxiliaries are tensors of the launch plan: a program that would
     # exceed the argument block's slots keeps its windows as written)
-    if len(derived.symbol_table) + len(derived.param_stmts) <= MAX_TENSORS:
+    if len(derived.symbol_table) + len(derived.param_stmts) <= MAX_TENSORS \
+        and same_boxes(derived):
       stencil = derived
   mod = Module(stencil)
   if opts.strategy == 'lds':

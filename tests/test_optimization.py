@@ -122,3 +122,54 @@ def test_lowering_uses_the_derived_program_and_can_be_told_not_to():
   assert 'xm_t0_output' in on.source and 'tmp_min0_16' not in on.source
   direct = lower.lower(st, lower.LowerOptions(vec=4, strategy='direct'))
   assert len(direct.stencil.local_stmts) == 11      # chains in both directions
+
+
+OFF_CENTRE_LOCAL = """kernel: offc
+burst width: 64
+unroll factor: 2
+iterate: 2
+border: preserve
+input float: a(32, *)
+local float: l(0, -1) = a(1, 0) + 1.0f
+output float: b(0, 0) = l(0, -1) * 0.5f
+"""
+
+
+def test_rewrites_keep_the_outputs_windows():
+  """A local stored off-centre and read back at that very offset is pointwise
+  -- but its own cell has to lie in the grid, so row 0 of `b` (which needs row
+  -1 of `l`) is NOT computable and keeps its input under `border: preserve`.
+  Folded into `b` the constraint would vanish: the lowering keeps the program
+  as written when a rewrite would change an output's window."""
+  from soda_amd import core
+  from soda_amd.codegen.hip import lower
+  from soda_amd.optimization import pointwise
+  st = core.from_text(OFF_CENTRE_LOCAL)
+  assert st.interior_bounds('b') == ((0, -1), (1, 0))
+  folded = pointwise.inline_pointwise(st)
+  assert [s.name for s in folded.ordered_stages] == ['b']
+  assert folded.interior_bounds('b') != st.interior_bounds('b')
+  for strategy in ('auto', 'direct'):
+    mod = lower.lower(st, lower.LowerOptions(strategy=strategy, fuse=(2,)))
+    assert [s.name for s in mod.stencil.ordered_stages] == ['l', 'b']
+    assert mod.stencil.interior_bounds('b') == st.interior_bounds('b')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('strategy,fuse', [('auto', (2,)), ('auto', ()),
+                                           ('direct', ())])
+def test_off_centre_local_under_preserved_border(built, strategy, fuse):
+  import numpy as np
+  from oracle import c_oracle, numpy_oracle
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  st = core.from_text(OFF_CENTRE_LOCAL)
+  extent = (300, 90)
+  a = np.random.default_rng(3).random(extent[::-1], dtype=np.float32)
+  want = numpy_oracle.run(st, {'a': a})['b']
+  assert np.array_equal(want, c_oracle.COracle(st, openmp=False).run({'a': a})['b'])
+  assert np.array_equal(want[0], a[0])          # row 0 keeps the input
+  with runtime.Program(st, lower.LowerOptions(strategy=strategy, fuse=fuse),
+                       extent=extent) as prog:
+    got = prog.run({'a': a})['b']
+  assert np.array_equal(got, want)

@@ -12,7 +12,8 @@ from soda_amd.codegen.hip import lower
 seed, kind = int(sys.argv[1]), sys.argv[2]
 extent, kw = ast.literal_eval(sys.argv[3]), ast.literal_eval(sys.argv[4])
 text, dim, _ = (fuzz.window_program(seed) if kind == 'window' else fuzz.program(seed, rich=kind == 'rich'))
-stencil = core.from_text(text)
+border = os.environ.get('TRIAGE_BORDER')
+stencil = core.from_text(text, **({'border': border} if border else {}))
 ins = fuzz.inputs_for(stencil, extent, seed)
 want = c_oracle.COracle(stencil, openmp=False).run(ins)
 
@@ -26,8 +27,10 @@ def check(kw, tag):
     out = []
     for o in stencil.output_names:
         lo, hi = stencil.valid_box(extent, o)
+        if border:
+            lo, hi = (0,) * len(extent), tuple(extent)
         idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
-        bad = got[o][idx] != want[o][idx]
+        bad = ~((got[o][idx] == want[o][idx]) | ((got[o][idx] != got[o][idx]) & (want[o][idx] != want[o][idx])))
         w = np.argwhere(bad)
         out.append((o, int(bad.sum()), (w.min(0) + np.array(lo[::-1])).tolist() if len(w) else None,
                     (w.max(0) + np.array(lo[::-1])).tolist() if len(w) else None,

@@ -164,18 +164,22 @@ def options_scan(first, last, only=None):
     kind = ['plain', 'window', 'window', 'rich'][int(rng.integers(4))]
     text, dim, iterate = (fuzz.window_program(seed) if kind == 'window' else
                           fuzz.program(seed, rich=kind == 'rich'))
-    if dim == 1 or (only and only not in text):
+    if only and only not in text:
       continue
+    border = 'preserve' if rng.random() < 0.25 else None
     try:
-      stencil = core.from_text(text)
+      stencil = core.from_text(text, **({'border': border} if border else {}))
+      if border:
+        stencil.check_preserve()
     except util.SodaError:
       continue
-    extent = ((int(rng.choice([300, 520, 777, 1100])), int(rng.integers(60, 260)))
+    extent = ((int(rng.integers(900, 5000)),) if dim == 1 else
+              (int(rng.choice([300, 520, 777, 1100])), int(rng.integers(60, 260)))
               if dim == 2 else
               (int(rng.choice([64, 130, 300])), int(rng.integers(12, 40)),
                int(rng.integers(20, 70))))
     lo, hi = stencil.valid_box(extent)
-    if not all(h > l for l, h in zip(lo, hi)):
+    if not border and not all(h > l for l, h in zip(lo, hi)):
       continue
     pick = lambda xs: xs[int(rng.integers(len(xs)))]
     kw = dict(strategy=pick(['auto', 'auto', 'auto', 'direct']) if only else 'auto',
@@ -196,7 +200,8 @@ def options_scan(first, last, only=None):
       kw['waves_y'] = 2
     ins = fuzz.inputs_for(stencil, extent, seed)
     want = c_oracle.COracle(stencil, openmp=False).run(ins)
-    what = 'seed %d %s extent %s %s' % (seed, kind, extent, kw)
+    what = 'seed %d %s%s extent %s %s' % (seed, kind, ' preserve' if border else '',
+                                          extent, kw)
     try:
       with runtime.Program(stencil, lower.LowerOptions(**kw),
                            extent=extent) as prog:
@@ -209,9 +214,12 @@ def options_scan(first, last, only=None):
       continue
     ran += 1
     for o in stencil.output_names:
-      lo, hi = stencil.valid_box(extent, o)
-      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
-      g, w = got[o][idx], want[o][idx]
+      if border:                       # the whole grid is defined
+        g, w = got[o], want[o]
+      else:
+        lo, hi = stencil.valid_box(extent, o)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+        g, w = got[o][idx], want[o][idx]
       if not np.array_equal(g, w, equal_nan=True):
         failed += 1
         print('%s output %s: %d cells differ\n%s' %
