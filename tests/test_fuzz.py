@@ -11,7 +11,7 @@ import fuzz
 from soda_amd import core, util
 
 CPU_SEEDS = range(0, 40)
-GPU_SEEDS = range(0, 160)
+GPU_SEEDS = range(0, 100)
 
 
 def _build(seed):
