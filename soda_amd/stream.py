@@ -72,6 +72,11 @@ def stencil_offsets(stencil: core.Stencil) -> Dict[str, int]:
   out = {}
   for s in stencil.output_stmts:
     pts = stencil.stencil_window_points(s.name)
+    if not pts:
+      # (a constant: the reference's host would take max() of an empty window)
+      raise util.SemanticError(
+          'wire format: output `%s` depends on no input, it has no stencil '
+          'window' % s.name)
     out[s.name] = core.get_stencil_distance(pts, tile) - util.serialize(
         core.get_stencil_window_offset(pts), tile)
   return out
@@ -92,6 +97,12 @@ class WireLayout:
     self.epc = {s.name: st.burst_width // table[s.name].width_in_bits *
                 self.bank_count[s.name] for s in stmts}                # :120-122
     window = st.stencil_window
+    if not window:
+      # (the first output reads no input at all -- a constant: the reference's
+      # host would take max() of an empty window here)
+      raise util.SemanticError(
+          'wire format: output `%s` depends on no input, the stencil has no '
+          'window' % st.output_names[0])
     self.stencil_dim = core.get_stencil_dim(window)
     self.stencil_distance = st.stencil_distance
     tile = st.tile_size

@@ -171,3 +171,17 @@ def test_wire_chain_with_several_inputs(name, extent):
   for o in st.output_names:
     assert got[o][idx].any()
     assert np.array_equal(got[o][idx], want[o][idx])
+
+
+def test_outputs_without_a_window_are_refused():
+  """An output that reads no input (a constant) has no stencil window: the
+  reference host would take max() of an empty set; here a SemanticError says
+  so (found by tools/fuzz_scan.py wire as an IndexError / ValueError)."""
+  from soda_amd import core, stream, util
+  head = 'kernel: k\nburst width: 64\nunroll factor: 2\niterate: 1\n' \
+         'input float: a(32, *)\n'
+  for body in ('output float: b(0, 0) = 0.5f\n',
+               'output float: b(0, 0) = a(0, 1)\noutput float: c(0, 0) = 2.0f\n'):
+    st = core.from_text(head + body)
+    with pytest.raises(util.SemanticError, match='no input'):
+      stream.WireLayout(st, (28, 20))

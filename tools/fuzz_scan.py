@@ -4,7 +4,8 @@ generic generator (tests/fuzz.py program) and the window generator
 (window_program), GPU kernels (auto and direct) against the C oracle, bit for
 bit; `group`: the same programs cut into virtual slabs (group_scan).
 `options`: random backend knobs on larger grids (options_scan).
-Usage: python tools/fuzz_scan.py window|generic|rich|group|options FIRST LAST"""
+`wire`: behind the reference host's stream format (wire_scan).
+Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire FIRST LAST"""
 import os
 import sys
 import time
@@ -232,7 +233,89 @@ def options_scan(first, last, only=None):
   return 1 if failed else 0
 
 
+def wire_scan(first, last):
+  """Random programs behind the reference host's wire format:
+  scatter as the reference host does, run <app>_kernel's dense / linear forms
+  on the banked streams, gather, compare with the stream-level restatement
+  (oracle/frt_layout.kernel_on_streams) and -- single-tile layouts -- the n-D
+  oracle on the common valid box."""
+  import fuzz
+  from oracle import frt_layout, numpy_oracle
+  from soda_amd import core, stream, util
+  ran = failed = refused = 0
+  t0 = time.time()
+  for seed in range(first, last):
+    rng = np.random.default_rng(seed + 91000)
+    kind = ['plain', 'plain', 'window', 'rich'][int(rng.integers(4))]
+    text, dim, _ = (fuzz.window_program(seed) if kind == 'window' else
+                    fuzz.program(seed, rich=kind == 'rich'))
+    if dim == 1:
+      continue
+    try:
+      stencil = core.from_text(text)
+    except util.SodaError:
+      continue
+    tiles = rng.random() < 0.3
+    if dim == 2:
+      extent = (int(rng.integers(70, 130)) if tiles else int(rng.integers(20, 33)),
+                int(rng.integers(12, 40)))
+    else:
+      extent = (int(rng.integers(40, 70)) if tiles else int(rng.integers(20, 33)),
+                int(rng.integers(12, 33)), int(rng.integers(8, 16)))
+    boxes = [stencil.valid_box(extent, o) for o in stencil.output_names]
+    lo = [max(b[0][d] for b in boxes) for d in range(dim)]
+    hi = [min(b[1][d] for b in boxes) for d in range(dim)]
+    if not all(h > l for l, h in zip(lo, hi)):
+      continue
+    mode = 'dense' if rng.random() < 0.6 else 'linear'
+    what = 'seed %d %s extent %s %s' % (seed, kind, extent, mode)
+    ins = fuzz.inputs_for(stencil, extent, seed)
+    try:
+      layout = stream.WireLayout(stencil, extent)
+      in_banks = frt_layout.scatter(layout, ins)
+      out_banks = frt_layout.alloc(layout, stencil.output_names)
+      prog = stream.StreamProgram(stencil, dense=mode != 'linear')
+    except (util.SodaError, ValueError, NotImplementedError) as e:
+      refused += 1
+      continue
+    try:
+      prog.run_banked_host(out_banks, in_banks, layout.cycle_count)
+      used = prog.last_mode
+    except util.SodaError as e:
+      failed += 1
+      print('%s: %s: %s\n%s' % (what, type(e).__name__, str(e)[:300], text),
+            flush=True)
+      continue
+    finally:
+      prog.close()
+    ran += 1
+    got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+           for o, t in zip(stencil.output_names, stencil.output_types)}
+    frt_layout.gather(layout, out_banks, got)
+    ref = {o: np.zeros_like(got[o]) for o in got}
+    frt_layout.gather(layout, frt_layout.kernel_on_streams(layout, in_banks), ref)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    bad = [o for o in stencil.output_names
+           if not np.array_equal(got[o][idx], ref[o][idx], equal_nan=True)]
+    if not bad and layout.tiles == 1:
+      want = numpy_oracle.run(stencil, ins)
+      bad = [o + ' (n-D oracle)' for o in stencil.output_names
+             if not np.array_equal(got[o][idx], want[o][idx], equal_nan=True)]
+    if bad:
+      failed += 1
+      print('%s (ran %s, %d tiles) outputs %s differ\n%s' %
+            (what, used, layout.tiles, bad, text), flush=True)
+    if ran % 25 == 0:
+      print('... %d programs, %d failures, %d refused, %.0f s' %
+            (ran, failed, refused, time.time() - t0), flush=True)
+  print('wire seeds [%d, %d): %d programs run, %d refused, %d failures' %
+        (first, last, ran, refused, failed))
+  return 1 if failed else 0
+
+
 if __name__ == '__main__':
+  if sys.argv[1] == 'wire':
+    sys.exit(wire_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'options':     # optional 4th argument: only programs containing it
     sys.exit(options_scan(int(sys.argv[2]), int(sys.argv[3]),
                           sys.argv[4] if len(sys.argv) > 4 else None))
