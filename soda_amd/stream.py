@@ -106,6 +106,12 @@ class WireLayout:
     self.stencil_dim = core.get_stencil_dim(window)
     self.stencil_distance = st.stencil_distance
     tile = st.tile_size
+    for d in range(dim - 1):
+      if tile[d] - self.stencil_dim[d] + 1 < 1:
+        # (the reference host would divide by zero / a negative step here)
+        raise util.SemanticError(
+            'wire format: the stencil window spans %d cells of dimension %d, '
+            'more than a tile of %d holds' % (self.stencil_dim[d], d, tile[d]))
     self.tile_count = [
         (self.extent[d] - self.stencil_dim[d]) //
         (tile[d] - self.stencil_dim[d] + 1) + 1 for d in range(dim - 1)

@@ -185,3 +185,13 @@ def test_outputs_without_a_window_are_refused():
     st = core.from_text(head + body)
     with pytest.raises(util.SemanticError, match='no input'):
       stream.WireLayout(st, (28, 20))
+
+
+def test_windows_wider_than_a_tile_are_refused():
+  from soda_amd import core, stream, util
+  taps = ' + '.join('a(%d, 0)' % i for i in range(-16, 17))
+  st = core.from_text('kernel: k\nburst width: 64\nunroll factor: 2\n'
+                      'iterate: 1\ninput float: a(32, *)\n'
+                      'output float: b(0, 0) = %s\n' % taps)
+  with pytest.raises(util.SemanticError, match='more than a tile'):
+    stream.WireLayout(st, (100, 20))
