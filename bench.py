@@ -172,8 +172,8 @@ def rehearse(args, stencil, extent, fuses, options, stream, value_1gpu):
       fuse = 1
       if dry.fuse:
         fuse = max(dry.fuse)
-      ex = sdist.auto_exchange_every(stencil, extent, n, args.iterate,
-                                     multiple_of=fuse)
+      ex = sdist.planned_exchange_every(stencil, extent, n, args.iterate,
+                                        options(fuses), multiple_of=fuse)
       slab = sdist.Slab(stencil, extent, n, n // 2, ex)
       lext = slab.local_extent
       with runtime.Program(stencil, options(fuses), extent=lext,
@@ -382,8 +382,18 @@ def main():
     if fuse > 1:
       ex = max(fuse, ex // fuse * fuse)
   else:
-    ex = sdist.auto_exchange_every(stencil, extent, geo_world, args.iterate,
-                                   multiple_of=fuse)
+    # the library's cost choice (pass times of the slab extent a candidate
+    # implies against a transfer model; soda_hip_group_plan, no GPU needed),
+    # the quarter-slab rule if it cannot be made.  Every rank must use the same
+    # interval: rank 0's counts
+    ex = sdist.planned_exchange_every(stencil, extent, geo_world, args.iterate,
+                                      options(fuses), multiple_of=fuse,
+                                      overlap=args.overlap != 'off')
+    if tdist is not None and world > 1:
+      t = torch.tensor([ex], dtype=torch.int64,
+                       device=dev if backend == 'nccl' else 'cpu')
+      tdist.broadcast(t, 0)
+      ex = int(t.item())
   slab = sdist.Slab(stencil, extent, geo_world, geo_rank, ex)
   if emulate > 1:
     if sdist.rounds(args.iterate, ex) > 1:

@@ -461,3 +461,32 @@ def test_bench_launcher_on_the_gpu_box():
                      timeout=300)
     assert run.returncode == 2 and 'needs 2 GPUs' in run.stderr
     assert not run.stdout.strip()
+
+
+def test_exchange_interval_by_the_librarys_cost_choice(built):
+  """dist.planned_exchange_every: the rank-per-GPU path asks the library
+  (soda_hip_group_plan, a pure function) like the one-process group does; the
+  headline run keeps its single interval, the long runs exchange a little less
+  often than the quarter-slab rule would, and every answer is a whole number of
+  the deepest pass and leaves slabs thicker than their ghosts."""
+  from soda_amd import core, dist as sdist
+  from soda_amd.codegen.hip import lower
+  fuse = (13, 12, 8, 4)
+  st = core.from_file(soda_path('jacobi2d.soda'), iterate=100)
+  for world in (2, 4, 8):
+    assert sdist.planned_exchange_every(
+        st, (8192, 8192), world, 100, lower.LowerOptions(fuse=fuse), 13) == 100
+  assert sdist.planned_exchange_every(st, (8192, 8192), 1, 100) == 100
+  long = core.from_file(soda_path('jacobi2d.soda'), iterate=1000)
+  k = sdist.planned_exchange_every(long, (8192, 8192), 8, 1000,
+                                   lower.LowerOptions(fuse=fuse), 13)
+  assert k % 13 == 0 and 100 <= k <= 1024
+  sdist.Slab(long, (8192, 8192), 8, 3, k)          # (raises if too thin)
+  h = core.from_file(soda_path('heat3d.soda'), iterate=50)
+  k = sdist.planned_exchange_every(h, (512, 512, 512), 8, 50,
+                                   lower.LowerOptions(fuse=(2,)), 2)
+  assert k % 2 == 0 and 2 <= k <= 32
+  sdist.Slab(h, (512, 512, 512), 8, 3, k)
+  # a description the library refuses falls back to the rule
+  assert sdist.planned_exchange_every(st, (8192, 8), 8, 100) == \
+      sdist.auto_exchange_every(st, (8192, 8), 8, 100)
