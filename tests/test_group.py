@@ -414,3 +414,47 @@ def test_baseline_multi_gpu_configs_as_eight_virtual_slabs(built, config):
                        extent=extent) as prog:
     single = prog.run({inp: field})[out]
   assert np.array_equal(got[idx], single[idx])
+
+
+def test_split_passes_with_a_one_sided_reach(built):
+  """Launch planning for a program that reaches upward only (ONE_SIDED): a slab
+  has ghost rows above and none below, sends rows below and none above; the
+  boundary chunks of the first / last pass sit on ONE side of the grid, and by
+  brute force no interior chunk of a first pass reads a ghost row, none of a
+  last pass delivers a row the neighbour below fetches."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_text(ONE_SIDED, iterate=8)
+  extent = (512, 300)
+  opts = runtime.resolve_options(stencil, lower.LowerOptions(fuse=(4,)), extent)
+  mod = lower.lower(stencil, opts)
+  code = runtime.compile_source(mod.source, '%s.hip' % stencil.app_name)
+  plan = runtime.make_plan(mod, runtime.kernel_resources(code))
+  reach_lo, reach_hi = stencil.reach_along(1)
+  assert (reach_lo, reach_hi) == (0, 1)
+  rows, ghost = extent[-1], 8
+  seen = 0
+  for below, above in ((True, True), (False, True), (True, False)):
+    g_hi = ghost * reach_hi if above else 0        # ghosts: above only
+    keep = (0, rows - g_hi)
+    run = runtime.SlabRun(keep[0], keep[1], reach_lo, reach_hi, 0, g_hi, 0, 0,
+                          1 if g_hi else None, 1)
+    run.send_lo = ghost * reach_hi if below else 0   # the slab below fetches
+    run.send_hi = 0                                  # nobody above does
+    launches = runtime.plan_launches(plan, extent, 8, run)
+    assert sum(l['fused_iters'] for l in launches) == 8
+    for l in launches:
+      if not l['split']:
+        continue
+      seen += 1
+      t, n = l['fused_iters'], l['hi'] - l['lo']
+      for c in range(l['bnd_lo'], l['bnd_hi']):      # the interior chunks
+        first = l['lo'] + c * l['chunk']
+        end = l['lo'] + min((c + 1) * l['chunk'], n)
+        if l['wait'] and g_hi:
+          assert end + t * reach_hi <= rows - g_hi
+        if l['record'] and run.send_lo:
+          assert first >= keep[0] + run.send_lo
+      if l['wait'] and not l['record']:
+        assert l['bnd_lo'] == 0          # nothing to wait for at the low end
+  assert seen
