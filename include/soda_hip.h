@@ -290,7 +290,17 @@ int soda_hip_run_device_cone(soda_hip_program_t* program,
  * the exchange first (environment SODA_HIP_SPLIT=side: the boundary chunks on
  * a stream the program owns, ordered against `stream` by events, so the parts
  * share the GPU -- measured slower).  Passes that are not one
- * marching kernel along the last dimension run whole: wait, compute, signal.  The reference has no counterpart (one
+ * marching kernel along the last dimension run whole: wait, compute, signal.
+ * What the library cannot see is who still READS the arrays a call writes: a
+ * neighbour that fetches rows of this slab's state on ITS stream must have
+ * finished before a later call overwrites that state.  With a two-sided reach
+ * the event chain implies it (its fetch -> its next pass -> its `sendable` ->
+ * my next exchange -> my `ghosts_ready`); with a one-sided reach -- a slab
+ * that sends to a neighbour it never receives from -- the caller has to order
+ * `stream` behind that neighbour's fetch itself (soda_group.cpp does; a
+ * transport that batches a rank's sends with its receives, like
+ * dist.StreamOverlap, is covered by `ghosts_ready`).
+ * The reference has no counterpart (one
  * device, frt/host.py:319-322); SURVEY.md 8(e): "compute boundary planes
  * first, send, compute interior". */
 typedef struct soda_hip_slab_run {
