@@ -51,11 +51,11 @@ def parse_args():
       ROOT, 'tests', 'golden', 'soda', 'jacobi2d.soda'))
   ap.add_argument('--extent', type=int, nargs='+', default=[8192, 8192])
   ap.add_argument('--iterate', type=int, default=100)
-  ap.add_argument('--fuse', type=int, nargs='+', default=[13, 12, 8, 4],
+  ap.add_argument('--fuse', type=int, nargs='+', default=None,
                   help='iterations one launch may fuse (temporal blocking); '
                   'the library mixes the depths per extent so that they add '
                   'up to iterate at the least total time (100 = 4 x 13 + '
-                  '4 x 12)')
+                  '4 x 12); default: soda_amd.codegen.hip.lower.DEFAULT_FUSE')
   ap.add_argument('--chunk-rows', type=int, default=None,
                   help='rows per wave; default: sized per kernel and GPU')
   ap.add_argument('--prefetch', type=int, default=None)
@@ -85,6 +85,12 @@ def parse_args():
                   help='with --group: all N slabs on GPU 0')
   ap.add_argument('--no-rehearsal', action='store_true')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-parity', action='store_true',
+                  help='skip the result check against the CPU oracle that '
+                  'follows the timed region')
+  ap.add_argument('--clock-warm-seconds', type=float, default=0.5,
+                  help='upper bound of the untimed spin in front of the timed '
+                  'region (steps until two 10-step windows agree within 1 %%)')
   ap.add_argument('--no-single-iter', action='store_true')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='target CPU time of the cpu_baseline sample')
@@ -314,6 +320,9 @@ def launch_ranks(args) -> int:
 
 def main():
   args = parse_args()
+  if args.fuse is None:
+    from soda_amd.codegen.hip import lower as _lower
+    args.fuse = list(_lower.DEFAULT_FUSE)
   # the C-ABI library is a build artefact (git-ignored): make sure it exists;
   # a no-op when it is newer than its sources
   import __graft_entry__ as entry
@@ -408,20 +417,26 @@ def main():
   stream = torch.cuda.current_stream().cuda_stream
 
   # synthetic input: the same seeded global field on every rank, sliced
-  gen = torch.Generator(device=dev)
-  gen.manual_seed(1234)
   shape = tuple(extent[::-1])
   np_dtypes = {'float32': torch.float32, 'float64': torch.float64,
                'uint16': torch.int16, 'int16': torch.int16,
                'int32': torch.int32}
+
+  def seeded_fields():
+    """The global input fields, one after the other (a generator: 256 MiB each
+    at the headline size) -- the same on every rank and on every call."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    for name, t in zip(stencil.input_names, stencil.input_types):
+      dt = np_dtypes[t.np_name]
+      if dt.is_floating_point:
+        yield torch.rand(shape, generator=gen, device=dev, dtype=dt)
+      else:
+        yield torch.randint(0, 30000, shape, generator=gen, device=dev,
+                            dtype=dt)
+
   a_bufs, b_bufs, c_bufs = [], [], []
-  for name, t in zip(stencil.input_names, stencil.input_types):
-    dt = np_dtypes[t.np_name]
-    if dt.is_floating_point:
-      full = torch.rand(shape, generator=gen, device=dev, dtype=dt)
-    else:
-      full = torch.randint(0, 30000, shape, generator=gen, device=dev,
-                           dtype=dt)
+  for full in seeded_fields():
     a_bufs.append(full[slab.begin:slab.end].clone())
     del full
     b_bufs.append(torch.empty_like(a_bufs[-1]))
@@ -429,13 +444,18 @@ def main():
       c_bufs.append(torch.empty_like(a_bufs[-1]))
   torch.cuda.synchronize()
 
+  hider = sdist.StreamOverlap(local_rank) if world > 1 else None
+
   def step_fn(dst, src, lext, iters, **kw):
     kw.setdefault('keep', slab.keep)
+    if hider is not None and not kw.get('sendable'):
+      # a run that records no `sendable` (a serial step, a timing loop): the
+      # next overlapped exchange must wait for everything on the launch stream
+      hider.invalidate()
     prog.run_device([t.data_ptr() for t in dst], [t.data_ptr() for t in src],
                     lext, iterate=iters, stream=stream, origin=slab.origin,
                     global_extent=slab.extent, **kw)
 
-  hider = sdist.StreamOverlap(local_rank) if world > 1 else None
   mode = {'overlap': world > 1 and args.overlap != 'off'}
 
   # A sustained iterated run: the input of a step is the output of the step
@@ -591,31 +611,48 @@ def main():
     # both ways, a few steps each; every rank must take the same decision
     trial = {}
     failed = None
-    for way in (True, False, True, False):
-      if way and failed:
-        continue
-      mode['overlap'] = way
-      dt = 0.0
+
+    def guarded(n_steps):
+      """n_steps steps; never raises: every rank reaches the collective that
+      follows whatever happened here (a rank that left the sequence would
+      leave the others in a barrier nobody completes)."""
       try:
-        one_step()
-        torch.cuda.synchronize()
-        tdist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(n_steps):
           one_step()
         torch.cuda.synchronize()
+        return None
+      except Exception as e:          # noqa: BLE001
+        return '%s: %s' % (type(e).__name__, str(e)[:200])
+
+    def any_rank(err):
+      t = torch.tensor([1.0 if err else 0.0], device=dev, dtype=torch.float64)
+      tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+      return float(t.item()) > 0
+
+    for way in (True, False, True, False):
+      if way and failed:              # (set from a reduced flag: same everywhere)
+        continue
+      mode['overlap'] = way
+      err = guarded(1)
+      bad = any_rank(err)             # doubles as the barrier in front of the clock
+      dt = 0.0
+      if not bad:
+        t0 = time.perf_counter()
+        err = guarded(3)
         dt = time.perf_counter() - t0
-      except Exception as e:       # the overlapped way is new on real links:
-        if not way:                # it must not take the serial one down
-          raise
-        failed = '%s: %s' % (type(e).__name__, str(e)[:200])
-      # every rank learns whether ANY rank failed (and the slowest time)
-      t = torch.tensor([dt, 1.0 if (way and failed) else 0.0], device=dev,
+      t = torch.tensor([dt, 1.0 if err else 0.0], device=dev,
                        dtype=torch.float64)
       tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-      if way and float(t[1].item()) > 0:
-        failed = failed or 'another rank failed'
+      bad = bad or float(t[1].item()) > 0
+      if bad:
+        if not way:                   # the serial way is the fallback: give up
+          raise SystemExit('bench.py: the serial exchange failed: %s' %
+                           (err or 'on another rank'))
+        failed = err or 'another rank failed'
         trial[True] = float('inf')
+        # all ranks restart from the same point of the rotation
+        chain['cur'] = a_bufs
+        hider.invalidate()
         continue
       trial[way] = min(trial.get(way, 1e9), float(t[0].item()) / 3 * 1e3)
     mode['overlap'] = trial[True] <= trial[False]
@@ -638,6 +675,31 @@ def main():
   one_step()
   step_fn = step_fn_real
   torch.cuda.synchronize()
+  # Bring the GPU to the clocks it sustains, OUTSIDE the timed region: a step
+  # is ~1.2 ms, and 20 steps right after idle read 5-7 % slower than 200
+  # (round 3: driver 5.55e12 with --steps 20 --warmup 5, own 200-step runs
+  # 5.9e12).  Windows of 10 steps until two in a row agree within 1 %, at most
+  # --clock-warm-seconds; every rank takes the decision from MAX-reduced
+  # numbers, so all run the same number of steps (steps exchange halos).
+  clock_warm_steps, prev_window = 0, None
+  warm_begin = time.perf_counter()
+  while args.clock_warm_seconds > 0:
+    t0 = time.perf_counter()
+    for _ in range(10):
+      one_step()
+    torch.cuda.synchronize()
+    now = time.perf_counter()
+    pair = [now - t0, now - warm_begin]
+    if tdist is not None:
+      t = torch.tensor(pair, device=dev, dtype=torch.float64)
+      tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+      pair = [float(v) for v in t.tolist()]
+    clock_warm_steps += 10
+    settled = prev_window is not None and \
+        abs(pair[0] - prev_window) <= 0.01 * prev_window
+    prev_window = pair[0]
+    if settled or pair[1] >= args.clock_warm_seconds:
+      break
   barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
@@ -703,6 +765,7 @@ def main():
       'rccl_world': rccl_world,
       **({'emulated_n_gpus': emulate} if emulate > 1 else {}),
       'steps': args.steps, 'warmup': args.warmup,
+      'clock_warm_steps': clock_warm_steps,
       'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
       'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
       'data': 'synthetic',
@@ -740,6 +803,68 @@ def main():
       'roofline': roofline,
   }
 
+  # ---- result check (outside the timed region) -------------------------------
+  # The reference's generated host checks every run it times, in the same
+  # process (frt/host.py:545-553 run, :625-657 compare).  Here: ONE more step
+  # -- the same programs, schedule, exchange mode and code path as the timed
+  # ones -- from the seeded input, the ranks' own rows gathered on rank 0 and
+  # compared with the CPU oracle (test infrastructure, used as the checker
+  # only) on the valid box, bit for bit.
+  if not args.no_parity and emulate <= 1:
+    host_in = {}
+    for i, (name, full) in enumerate(zip(stencil.input_names,
+                                         seeded_fields())):
+      a_bufs[i].copy_(full[slab.begin:slab.end])
+      if rank == 0:
+        host_in[name] = full.cpu().numpy().view(
+            stencil.input_types[i].np_name)
+      del full
+    chain['cur'], chain['first'] = a_bufs, True
+    if hider is not None:
+      hider.invalidate()
+    res = one_step()
+    torch.cuda.synchronize()
+    own = [r[slab.ghost_lo:slab.ghost_lo + slab.own_rows] for r in res]
+    if world > 1:
+      most = -(-extent[-1] // world)
+      gathered = []
+      for t in own:
+        pad = torch.zeros((most,) + tuple(t.shape[1:]), dtype=t.dtype,
+                          device=dev if backend == 'nccl' else 'cpu')
+        pad[:t.shape[0]].copy_(t)
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        tdist.all_gather(parts, pad)
+        rows_of = [extent[-1] // world + (1 if r < extent[-1] % world else 0)
+                   for r in range(world)]
+        gathered.append(torch.cat([p[:n] for p, n in zip(parts, rows_of)]))
+      own = gathered
+    if rank == 0:
+      import numpy as np
+      from oracle import c_oracle
+      t0 = time.time()
+      want = c_oracle.COracle(stencil, openmp=True).run(host_in)
+      cells_checked = bad = 0
+      for t, o in zip(own, stencil.output_names):
+        got = t.cpu().numpy().view(want[o].dtype)
+        lo, hi = stencil.valid_box(extent, o)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+        g, w = got[idx], want[o][idx]
+        if g.dtype.kind == 'f':
+          bits = {4: np.uint32, 8: np.uint64}[g.dtype.itemsize]
+          g = np.ascontiguousarray(g).view(bits)
+          w = np.ascontiguousarray(w).view(bits)
+        cells_checked += int(g.size)
+        bad += int((g != w).sum())
+      result['parity'] = {
+          'cells': cells_checked, 'mismatches': bad,
+          'against': 'oracle/c_oracle.py (OpenMP), %d iterations from the '
+                     'seeded input, valid box, bit for bit; %.1f s' %
+                     (args.iterate, time.time() - t0),
+          'what_ran': 'one more step after the timed region: same program, '
+                      'schedule and exchange mode',
+      }
+      del want, host_in
+
   if world == 1 and rank == 0:
     if not args.no_single_iter and fuse > 1:
       prog1 = runtime.Program(stencil, options([1]), device=local_rank,
@@ -776,6 +901,10 @@ def main():
     print(json.dumps(result))
   if tdist is not None:
     tdist.destroy_process_group()
+  if rank == 0 and result.get('parity', {}).get('mismatches'):
+    sys.stderr.write('bench.py: the checked step differs from the oracle in '
+                     '%d cells\n' % result['parity']['mismatches'])
+    sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -380,7 +380,13 @@ int soda_hip_program_calibrate(soda_hip_program_t* program,
  * synchronises `stream` once and costs a few milliseconds -- so that every
  * caller, the generated C++ host included, is scheduled by the clock, not by
  * the model (whose error is ~9 % per pass).  on = 0 turns that off for a
- * program; the environment variable SODA_HIP_NO_CALIBRATE=1 for all. */
+ * program; the environment variable SODA_HIP_NO_CALIBRATE=1 for all.
+ * Two kinds of run never calibrate by themselves and stay asynchronous on
+ * `stream` as documented: a soda_hip_run_device_slab call that is handed an
+ * event (other streams are live beside it: the calibration's allocations and
+ * its synchronisation would stall the neighbours' exchange), and any run on a
+ * stream that is being captured into a graph.  Calibrate such extents
+ * beforehand with soda_hip_program_calibrate, or they run by the model. */
 int soda_hip_program_set_auto_calibrate(soda_hip_program_t* program, int on);
 /* Time of one launch of every pass on `extent` in ns (num_passes values):
  * measured if calibrated (*measured = 1), else the model's. */

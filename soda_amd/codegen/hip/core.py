@@ -44,10 +44,11 @@ def add_arguments(parser) -> None:
                       help='kernel family: register-marching wavefront strips '
                       '(2-D / 3-D programs) or the direct kernels')
   parser.add_argument('--hip-fuse', type=int, nargs='*', dest='hip_fuse',
-                      metavar='T', default=[13, 12, 8, 4],
+                      metavar='T', default=list(lower.DEFAULT_FUSE),
                       help='temporal blocking: the numbers of iterations a '
                       'launch may fuse; the library mixes them per extent '
-                      '(default: 13 12 8 4; depths that do not fit the registers '
+                      '(default: %s; depths that do not fit the registers ' %
+                      ' '.join(map(str, lower.DEFAULT_FUSE)) +
                       'are dropped, 3-D programs fuse at most 2)')
   parser.add_argument('--hip-vec', type=int, dest='hip_vec', metavar='V',
                       help='cells per lane per row (default: 16 bytes worth)')

@@ -55,6 +55,11 @@ from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_FUSE_PRESERVE,  # noqa:
 # ---------------------------------------------------------------------------
 
 MAX_TENSORS = 16       # SODA_HIP_MAX_TENSORS (include/soda_hip.h)
+# The fusion depths iterated programs are offered by default -- ONE definition
+# for `sodac --hip-fuse`, bench.py, __graft_entry__.prebuild_list and the parity
+# tests of the benched schedule (tests/test_hip_parity.py): the library mixes
+# them per extent (jacobi2d 8192^2 x 100 = 4 x T13 + 4 x T12).
+DEFAULT_FUSE = (13, 12, 8, 4)
 # integer sums along the streamed dimension as sliding sums in the marching
 # kernels (march.py `slide`) instead of power-of-two chains (SODA_HIP_SLIDE=0/1)
 SLIDING_SUMS = os.environ.get('SODA_HIP_SLIDE', '1') != '0'

@@ -886,7 +886,21 @@ int run_core(soda_hip_program_t* p, void* const* outputs,
   } else {
     ExtentKey key;
     for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) key[d] = base.extent[d];
-    if (p->auto_calibrate && !p->calibrating && iterate > 1 &&
+    // Never next to a halo exchange (the caller's events say other streams
+    // are live: a calibration allocates, frees and synchronises -- it would
+    // stall the neighbours and make every rank's schedule depend on who ran
+    // beside it), never on a capturing stream (synchronising is illegal
+    // there): such runs are scheduled by the model unless the caller
+    // calibrated the extent beforehand (soda_hip_program_calibrate).
+    const bool beside_exchange = slab && (slab->ghosts_ready || slab->sendable);
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (p->auto_calibrate && !p->calibrating && !beside_exchange)
+      if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+      }
+    if (p->auto_calibrate && !p->calibrating && !beside_exchange &&
+        capture == hipStreamCaptureStatusNone && iterate > 1 &&
         plan.num_passes > 1 && plan.num_inputs == plan.num_outputs &&
         !p->measured.count(key)) {
       // first run on this extent: let the clock rank the passes
@@ -1220,10 +1234,13 @@ int soda_hip_program_calibrate(soda_hip_program_t* p, const int32_t* extent,
         rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
                       one, stream_, i, nullptr);
         if (rc != SODA_HIP_OK) break;
-        (void)hipEventRecord(pair[0], stream);
+        if (hipEventRecord(pair[0], stream) != hipSuccess)
+          rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventRecord");
+        if (rc != SODA_HIP_OK) break;
         rc = run_core(p, outs.data(), ins.data(), key.data(), nullptr, nullptr,
                       one * launches, stream_, i, nullptr);
-        (void)hipEventRecord(pair[1], stream);
+        if (rc == SODA_HIP_OK && hipEventRecord(pair[1], stream) != hipSuccess)
+          rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipEventRecord");
       }
     if (rc == SODA_HIP_OK && hipStreamSynchronize(stream) != hipSuccess)
       rc = fail(SODA_HIP_ERR_RUNTIME, "calibrate: hipStreamSynchronize");

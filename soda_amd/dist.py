@@ -129,8 +129,35 @@ class StreamOverlap:
   Program.run_device(ghosts=..., sends=..., ghosts_ready=..., sendable=...),
   which launches the chunks next to the ghosts behind the one and fires the
   other ahead of the interior of its last pass (soda_hip_run_device_slab).
-  RCCL's send/recv kernels run on RCCL's own stream; `req.wait()` only orders
-  the exchange stream behind them, the host does not block."""
+  RCCL's send/recv kernels run on RCCL's stream; `req.wait()` only orders
+  the exchange stream behind them, the host does not block.
+
+  The event chain of one rank, interval j (compute stream C, exchange stream X;
+  state arrays rotate A -> B -> A ..., interval j reads cur_j, writes cur_j+1):
+
+    X:  wait sendable(j-1) | send own edge rows of cur_j, recv ghost rows of
+        cur_j | record ready(j)
+    C:  first pass: interior chunks | wait ready(j) | boundary chunks
+        ... middle passes (program temporaries only) ...
+        last pass: boundary chunks (deliver the send rows of cur_j+1 and are
+        the only launches that still write its ghost rows) | record
+        sendable(j) | interior chunks
+
+  Why nothing is overwritten while it is still read: (1) the exchange touches
+  cur_j only; the compute stream writes cur_j again in interval j+1 at the
+  earliest (it is that interval's output) and has waited for ready(j) -- which
+  sits behind the sends AND the receives of exchange j -- in interval j, also
+  when a slab has nothing to receive (one-sided reach: its first pass still
+  waits for its own sends).  (2) X receives into the ghost rows of cur_j+1
+  only behind sendable(j), after which no launch of interval j writes them.
+  (3) The neighbour's rows arrive behind ITS sendable(j-1): complete.
+  `sendable` is ONE event re-recorded every interval; X's wait is enqueued
+  after the run that records it has returned, so it binds to that record.
+
+  `sendable` only speaks for the run that recorded it.  If anything else was
+  enqueued on the compute stream since (a step without this object, a timing
+  loop, the caller's own kernels), call `invalidate()`: the next exchange then
+  waits for everything enqueued on the compute stream so far."""
 
   def __init__(self, device: int = 0):
     import torch
@@ -138,15 +165,21 @@ class StreamOverlap:
     self._torch = torch
     self.comm = torch.cuda.Stream(device=device)
     self.sendable = runtime.Event()
+    self.fence = runtime.Event()
     self.ready = [runtime.Event(), runtime.Event()]
     self.turn = 0
-    self.recorded = False     # has a run recorded `sendable` yet?
+    self.recorded = False     # did the step just before record `sendable`?
     self._lib = runtime.library()
 
+  def invalidate(self) -> None:
+    """The compute stream has run something that did not record `sendable`."""
+    self.recorded = False
+
   def start(self, slab: Slab, tensors: Sequence, dist_module, group=None,
-            main_stream: int = 0):
+            main_stream: Optional[int] = None):
     """Enqueues the exchange of `tensors`' ghost rows; returns the raw event
-    handle to wait for (0 when there is nothing to exchange)."""
+    handle to wait for (0 when there is nothing to exchange).  `main_stream`:
+    the compute stream's raw handle (default: torch's current stream)."""
     import ctypes
     from soda_amd import runtime
     if slab.world == 1:
@@ -154,10 +187,16 @@ class StreamOverlap:
     torch = self._torch
     comm_handle = ctypes.c_void_p(self.comm.cuda_stream)
     if self.recorded:
-      runtime.check(self._lib.soda_hip_hipstream_wait_event(
-          comm_handle, self.sendable._h), 'hipstream_wait_event')
-    else:       # nothing recorded it yet: behind everything enqueued so far
-      self.comm.wait_stream(torch.cuda.current_stream())
+      behind = self.sendable
+    else:       # nothing speaks for the rows: behind everything enqueued so far
+      if main_stream is None:
+        main_stream = torch.cuda.current_stream().cuda_stream
+      self.fence.record(main_stream)
+      behind = self.fence
+    runtime.check(self._lib.soda_hip_hipstream_wait_event(
+        comm_handle, behind._h), 'hipstream_wait_event')
+    # consumed: only a step parameterised by step_kwargs renews it
+    self.recorded = False
     ops = []
     with torch.cuda.stream(self.comm):
       for t in tensors:
@@ -178,7 +217,9 @@ class StreamOverlap:
 
   def step_kwargs(self, slab: Slab, ghosts_ready: int):
     """Keyword arguments for Program.run_device of the interval that follows
-    `start` (ghosts_ready = what it returned; 0: the ghosts are fresh)."""
+    `start` (ghosts_ready = what it returned; 0: the ghosts are fresh).  The
+    caller MUST issue that run next on the compute stream: the exchange after
+    it is ordered behind the `sendable` this run records."""
     self.recorded = True
     k = slab.exchange_every
     return dict(

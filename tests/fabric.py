@@ -5,11 +5,23 @@ copy handed over through a queue.  `Fabric.endpoint(rank)` quacks like the
 batch_isend_irecv, barrier), so a multi-rank slab run -- every rank executing
 the REAL decomposition, exchange schedule and kernels -- can be rehearsed on
 the single GPU of a test box, where RCCL needs one device per rank."""
+import os
 import queue
 import threading
 from typing import List
 
 TIMEOUT_S = 300
+
+# Round-3 defect of THIS file, kept reproducible (tools/flake_loop.py): the
+# staging copy of a message is allocated on the sender's stream and read on the
+# receiver's.  Dropping the last reference right after ENQUEUEING the read hands
+# the block back to PyTorch's caching allocator, which knows of the sender's
+# stream only: the sender's next message may be staged in the same block while
+# the receiver's copy is still queued behind the events of a slower neighbour
+# -- the receiver then reads the NEXT interval's rows.  (The driver's round-3
+# GPU run: test_exchange_hidden_under_the_compute, 4 ranks, two messages per
+# exchange.)  SODA_FABRIC_UNSAFE_LIFETIME=1 brings the defect back.
+UNSAFE_LIFETIME = bool(os.environ.get('SODA_FABRIC_UNSAFE_LIFETIME'))
 
 
 class _Recv:
@@ -25,6 +37,10 @@ class _Recv:
       import torch
       torch.cuda.current_stream().wait_event(ready)
     self.tensor.copy_(payload)
+    if ready is not None and not UNSAFE_LIFETIME:
+      # the staging block stays the receiver stream's until this copy has run
+      import torch
+      payload.record_stream(torch.cuda.current_stream())
 
 
 class _Done:

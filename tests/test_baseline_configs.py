@@ -144,18 +144,20 @@ C4 = ('heat3d.soda', (512, 512, 512), 50)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('fuse', [(12, 4), (4,)])
+@pytest.mark.parametrize('fuse', ['bench', (12, 4), (4,)])
 def test_c5_jacobi2d_8192_iterate_1000(built, fuse):
   from soda_amd import core, runtime
   from soda_amd.codegen.hip import lower
   name, extent, iterate = C5
+  if fuse == 'bench':        # the depths bench.py / sodac default to (T13 ...)
+    fuse = lower.DEFAULT_FUSE
   stencil = core.from_file(soda_path(name), iterate=iterate)
   field = _field(extent, 3)
   with runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
                        extent=extent) as prog:
     got = prog.run({'t1': field})['t0']
     launches, fused = prog.last_launches()
-  assert launches <= (90 if fuse == (12, 4) else 250)
+  assert launches <= (250 if fuse == (4,) else 90)
   idx, lo, hi = _box(stencil, extent)
   assert (lo, hi) == ((1000, 1000), (7192, 7192))
   want = _oracle(name, extent, iterate, 3, 'random')

@@ -299,11 +299,26 @@ def test_two_ranks_on_gpu_kernels(tmp_path, name, extent, iterate, every, fuse,
   assert np.array_equal(got[idx], want[idx])
 
 
+UPWIND = """kernel: upwind
+burst width: 64
+unroll factor: 2
+iterate: 4
+input float: u(64, *)
+output float: v(0, 0) = (u(0, 0) + u(0, 1) + u(-1, 0) + u(1, 1)) * 0.25f
+"""
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,extent,iterate,every,fuse,world', [
     ('jacobi2d.soda', (1024, 1600), 40, 12, (12, 4), 4),
+    ('jacobi2d.soda', (1024, 1600), 39, 13, (13, 12, 8, 4), 4),  # benched depths
     ('jacobi2d.soda', (512, 480), 23, 4, (4,), 8),     # one pass per interval
     ('heat3d.soda', (64, 48, 96), 9, 2, (2,), 4),
+    # a one-sided reach: a rank fetches from the rank above and never from the
+    # one below -- nothing it receives keeps it from running ahead of the rank
+    # that still has to fetch its rows (the hole the slab group had, DESIGN 6)
+    (UPWIND, (512, 227), 10, 1, (), 6),
+    (UPWIND, (512, 454), 12, 4, (4,), 5),
 ])
 def test_exchange_hidden_under_the_compute(name, extent, iterate, every, fuse,
                                            world):
@@ -311,58 +326,65 @@ def test_exchange_hidden_under_the_compute(name, extent, iterate, every, fuse,
   every rank (a thread with a compute stream of its own; messages by
   tests/fabric.py, which orders the receiver's stream behind the sender's copy
   as RCCL does) runs its exchanges on a second stream while the rows that need
-  no fresh ghost compute; two chained runs, equal to the oracle bit for bit."""
-  import torch
-  import fabric
-  from soda_amd import core, dist as sdist, runtime
-  from soda_amd.codegen.hip import lower
+  no fresh ghost compute; two chained runs, equal to the oracle bit for bit --
+  also with one rank held back on the GPU and another on the host."""
+  import overlap_case
+  from soda_amd import core, dist as sdist
   from oracle import c_oracle
-  stencil = core.from_file(soda_path(name), iterate=iterate)
+
+  def load(iters):
+    if name.endswith('.soda'):
+      return core.from_file(soda_path(name), iterate=iters)
+    return core.from_text(name, iterate=iters)
+
+  stencil = load(iterate)
   rng = np.random.default_rng(5)
-  field = rng.random(tuple(extent[::-1]), dtype=np.float32)
-  splits = []
-
-  def rank_fn(rank, endpoint):
-    slab = sdist.Slab(stencil, extent, world, rank, every)
-    prog = runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
-                           extent=slab.local_extent)
-    compute = torch.cuda.Stream()
-    with torch.cuda.stream(compute):
-      hider = sdist.StreamOverlap(0)
-      src = [torch.from_numpy(field[slab.begin:slab.end].copy()).cuda()]
-      work = [[torch.empty_like(src[0])] for _ in range(2)]
-
-      def step(dst, cur, lext, iters, **kw):
-        prog.run_device([t.data_ptr() for t in dst],
-                        [t.data_ptr() for t in cur], lext, iterate=iters,
-                        stream=compute.cuda_stream, origin=slab.origin,
-                        global_extent=slab.extent, **kw)
-        splits.append(prog.last_split())
-
-      res = sdist.run(slab, src, work[0], work[1], step, iterate, endpoint,
-                      overlap=hider)
-      # chained: the state's ghosts are stale, the run opens with an exchange
-      pool = [src] + work
-      others = [x for x in pool if x[0] is not res[0]]
-      res = sdist.run(slab, res, others[0], others[1], step, iterate,
-                      endpoint, ghosts_fresh=False, overlap=hider)
-      compute.synchronize()
-      hider.comm.synchronize()
-      own = res[0][slab.ghost_lo:slab.ghost_lo + slab.own_rows].cpu().numpy()
-    prog.close()
-    return own, endpoint.messages
-
-  results = fabric.run_ranks(world, rank_fn)
-  got = np.concatenate([r[0] for r in results], axis=0)
+  fields = {n: rng.random(tuple(extent[::-1]), dtype=np.float32)
+            for n in stencil.input_names}
+  again = load(2 * iterate)
+  want = c_oracle.COracle(again).run(fields)
   rounds = sdist.rounds(iterate, every)
-  assert results[0][1] == 2 * rounds - 1 and results[1][1] == 2 * (2 * rounds - 1)
-  assert sum(splits) > 0, 'no pass was ever split'
-  again = core.from_file(soda_path(name), iterate=2 * iterate)
-  want = c_oracle.COracle(again).run({again.input_names[0]: field})[
-      again.output_names[0]]
-  lo, hi = again.valid_box(extent)
-  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
-  assert np.array_equal(got[idx], want[idx])
+  one_sided = 0 in stencil.reach_along(stencil.dim - 1)
+  with overlap_case.Case(stencil, extent, every, fuse, world) as case:
+    for knobs in (dict(), dict(spin={1: 3_000_000}, sleep={world - 1: 0.002})):
+      got, messages = case.trial(fields, iterate, runs=2, **knobs)
+      assert overlap_case.mismatches(again, extent, got, want,
+                                     2 * iterate) == 0, knobs
+      if one_sided:      # an end rank only sends or only receives
+        assert messages[1] == 2 * rounds - 1
+      else:
+        assert messages[0] == 2 * rounds - 1
+        assert messages[1] == 2 * (2 * rounds - 1)
+    assert one_sided or case.splits > 0, 'no pass was ever split'
+
+
+@pytest.mark.gpu
+def test_many_short_overlapped_intervals_stay_in_order():
+  """The rank-per-GPU counterpart of test_group.py's
+  test_many_short_intervals_stay_in_order: 300 intervals of two iterations on
+  six ranks, 30 chained runs, ranks skewed against each other on the GPU and on
+  the host -- no exchange and no pass may overtake what it depends on.
+  `border: preserve` keeps the whole grid defined, so every cell of the
+  600-iteration result is compared."""
+  import overlap_case
+  from soda_amd import core
+  from oracle import c_oracle
+  extent, world = (256, 636), 6
+  runs, per_run = 30, 20
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=per_run,
+                           border='preserve')
+  rng = np.random.default_rng(23)
+  fields = {'t1': rng.random(tuple(extent[::-1]), dtype=np.float32)}
+  total = core.from_file(soda_path('jacobi2d.soda'), iterate=runs * per_run,
+                         border='preserve')
+  want = c_oracle.COracle(total).run(fields)
+  with overlap_case.Case(stencil, extent, 2, (2,), world) as case:
+    got, messages = case.trial(fields, per_run, runs=runs,
+                               spin={2: 400_000}, sleep={4: 0.0003})
+    assert case.intervals == world * runs * per_run // 2
+  assert messages[0] == runs * per_run // 2 - 1
+  assert overlap_case.mismatches(total, extent, got, want, runs * per_run,
+                                 whole_grid=True) == 0
 
 
 def test_thin_slab_is_refused_on_every_rank():

@@ -528,6 +528,7 @@ def test_device_entry_and_errors(built):
 @pytest.mark.parametrize('name,extent,iterate,fuse', [
     ('jacobi2d.soda', (8192, 8192), 12, (4,)),
     ('jacobi2d.soda', (8192, 8192), 100, (12, 4)),     # BASELINE config 1/2
+    ('jacobi2d.soda', (8192, 8192), 100, 'bench'),     # ... as bench.py runs it
     ('blur.soda', (16384, 16384), 1, ()),              # BASELINE config 3
     ('heat3d.soda', (512, 512, 512), 6, ()),           # BASELINE config 4 grid
 ])
@@ -541,6 +542,9 @@ def test_full_size_properties(built, name, extent, iterate, fuse):
   from oracle import c_oracle
   stencil = core.from_file(soda_path(name), iterate=iterate)
   inputs = _inputs(stencil, extent, seed=11)
+  if fuse == 'bench':       # the depth set bench.py / sodac default to
+    fuse = lower.DEFAULT_FUSE
+    assert max(fuse) == 13
   with runtime.Program(stencil, lower.LowerOptions(fuse=fuse),
                        extent=extent) as prog:
     got = prog.run(inputs)
@@ -555,6 +559,57 @@ def test_full_size_properties(built, name, extent, iterate, fuse):
       unfused = prog.run(inputs)
     for o in stencil.output_names:
       assert np.array_equal(got[o], unfused[o])
+
+
+def test_every_kernel_of_the_benched_schedule_matches_the_oracle(built):
+  """What bench.py times is what is checked: the program it builds by default
+  (jacobi2d, lower.DEFAULT_FUSE, 8192 x 8192), and for EVERY pass the
+  library schedules for the 100-iteration step on that extent a run that
+  consists of launches of that pass alone (as bench.py's own per-kernel timing
+  does), on the full grid, against the OpenMP C oracle bit for bit.  The
+  kernel names are the ones the bench line reports (`roofline.kernel`,
+  `roofline.scheduled_kernels`).  The reference checks every run it times:
+  frt/host.py:545-553 (run), :625-657 (compare)."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  import conftest
+  extent, iterate = (8192, 8192), 100
+  stencil = core.from_file(soda_path('jacobi2d.soda'), iterate=iterate)
+  inputs = _inputs(stencil, extent, seed=29)
+  lo_hi = stencil.valid_box
+  with runtime.Program(stencil, lower.LowerOptions(fuse=lower.DEFAULT_FUSE),
+                       extent=extent, calibrate=True) as prog:   # as bench.py
+    sched = prog.schedule(extent, iterate)
+    assert sum(t * n for t, n in sched.items()) == iterate
+    by_depth = {p.fused_iters: prog.module.kernels[p.kernels[0]].name
+                for p in prog.module.sorted_passes()}
+    # the clock picks the mix (BENCH_r03: 4 x T13 + 4 x T12; the model alone:
+    # 7 x T12 + 2 x T8): whatever it picked here, plus the two deepest passes
+    # the bench line has named so far
+    depths = set(sched) | {13, 12}
+    checked = {}
+    for depth in sorted(depths, reverse=True):
+      n = 2
+      while n > 1 and prog.schedule(extent, depth * n) != {depth: n}:
+        n -= 1
+      assert prog.schedule(extent, depth * n) == {depth: n}
+      got = prog.run(inputs, iterate=depth * n)['t0']
+      assert prog.last_launches()[0] == n
+      want = c_oracle.COracle(stencil).run(inputs, iterate=depth * n)['t0']
+      lo, hi = lo_hi(extent, 't0', depth * n)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      assert np.array_equal(got[idx], want[idx]), by_depth[depth]
+      checked[by_depth[depth]] = depth * n
+      conftest.VERIFIED_KERNELS.add(by_depth[depth])
+    # and the step itself, as scheduled
+    got = prog.run(inputs)['t0']
+    want = c_oracle.COracle(stencil).run(inputs)['t0']
+    lo, hi = lo_hi(extent)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(got[idx], want[idx])
+  assert set(checked) >= {by_depth[d] for d in sched}
+  assert all('_T%d_' % d in by_depth[d] for d in depths)
 
 
 # (file, input decl override, extent, output decl override, mode): `dense` =
@@ -766,6 +821,10 @@ def test_rows_shared_by_the_waves_of_a_block(built, name, iterate, opts, extent,
     ('jacobi2d.soda', (520, 400), 17, (4,), (150, 400)),        # ... above
     ('heat3d.soda', (256, 24, 90), 10, (2,), (30, 60)),
     ('blur.soda', (640, 300), 6, (3,), (40, 200)),              # reaches 0 below, 2 above
+    # the slabs of the 8-GPU bench run (middle rank, end rank), benched depths
+    ('jacobi2d.soda', (8192, 1224), 100, 'bench', (100, 1124)),
+    ('jacobi2d.soda', (8192, 1124), 100, 'bench', (0, 1024)),
+    ('jacobi2d.soda', (8192, 1224), 26, (13,), (100, 1124)),
 ])
 def test_runs_that_keep_a_row_range_skip_the_rest(built, name, extent, iterate,
                                                   fuse, keep):
@@ -778,6 +837,8 @@ def test_runs_that_keep_a_row_range_skip_the_rest(built, name, extent, iterate,
   from soda_amd.codegen.hip import lower
   stencil = core.from_file(soda_path(name), iterate=iterate)
   ins = _inputs(stencil, extent, 7)
+  if fuse == 'bench':
+    fuse = lower.DEFAULT_FUSE
   opts = lower.LowerOptions(strategy='direct') if fuse == 'direct' else \
       lower.LowerOptions(fuse=fuse)
   with runtime.Program(stencil, opts, extent=extent) as prog:
@@ -804,6 +865,10 @@ def test_runs_that_keep_a_row_range_skip_the_rest(built, name, extent, iterate,
   k0, k1 = max(keep[0], lo[-1]) - lo[-1], min(keep[1], hi[-1]) - lo[-1]
   assert k1 > k0
   assert np.array_equal(a[k0:k1], b[k0:k1])
+  if extent[0] >= 8192:      # the bench's slabs: against the oracle as well
+    from oracle import c_oracle
+    want = c_oracle.COracle(stencil).run(ins)[stencil.output_names[0]][box]
+    assert np.array_equal(b[k0:k1], want[k0:k1])
 
 
 @pytest.mark.gpu
@@ -968,6 +1033,11 @@ def test_committed_golden_vectors_on_gpu(built, tag, soda, border, strategy):
     ('jacobi2d.soda', 24, dict(fuse=(12,)), (2050, 1031), None),   # V=2 rows
     ('jacobi2d.soda', 24, dict(fuse=(12,), pipe=4), (2052, 1031), None),
     ('jacobi2d.soda', 13, dict(fuse=(12, 4)), (1027, 517), None),  # V=1 rows
+    # the bench's deepest pass (4 halo lanes per side of a half strip, not 3)
+    ('jacobi2d.soda', 13, dict(fuse=(13,)), (2050, 1031), None),
+    ('jacobi2d.soda', 26, dict(fuse=(13,)), (1027, 517), None),
+    ('jacobi2d.soda', 26, dict(fuse=(13,)), (2304, 1100), None),   # V=4, ragged
+    ('jacobi2d.soda', 38, dict(fuse=(13, 12)), (4100, 700), None),
     ('jacobi2d.soda', 9, dict(fuse=(8,)), (1027, 517), 'preserve'),
     ('blur.soda', 1, dict(), (4100, 2057), None),                  # u16, V=4
     ('heat3d.soda', 6, dict(fuse=(2,)), (258, 131, 70), None),
