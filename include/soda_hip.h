@@ -280,11 +280,14 @@ int soda_hip_run_device_cone(soda_hip_program_t* program,
  *   send_lo / send_hi    rows [keep_lo, keep_lo + send_lo) and [keep_hi -
  *                        send_hi, keep_hi) of the RESULT are what the
  *                        neighbours fetch next.  The chunks of the last pass
- *                        that deliver them (and everything below / above:
- *                        the only launches that still write the result's
- *                        ghost rows) go first, `sendable` (a hipEvent_t,
- *                        recorded exactly once per call; NULL: none) fires
- *                        behind them, the rest of the pass follows -- the
+ *                        that deliver them, AND every chunk that writes a row
+ *                        outside [keep_lo, keep_hi) -- the result's ghost
+ *                        rows, which the next exchange overwrites -- whether
+ *                        or not that side sends anything (a one-sided reach
+ *                        has ghosts above and sends below), go first;
+ *                        `sendable` (a hipEvent_t, recorded exactly once per
+ *                        call; NULL: none) fires behind them; the rest of
+ *                        the pass follows and writes kept rows only -- the
  *                        next exchange may start while it computes.
  * A split pass is two launches on `stream`, the part that does not depend on
  * the exchange first (environment SODA_HIP_SPLIT=side: the boundary chunks on

@@ -32,6 +32,8 @@ C loop nests in oracle/kat_kernels.c, and agreement with the generated-C oracle
 Array convention: numpy shape is extent reversed (dimension 0 of the DSL is the
 fastest-varying one = the last numpy axis), C-contiguous.
 """
+import os
+import re
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -372,10 +374,25 @@ def run(stencil: core.Stencil, inputs: Dict[str, np.ndarray],
 # the reference harness's compare rule (frt/host.py:625-657)
 # ---------------------------------------------------------------------------
 
+def _atof(text: str) -> float:
+  """C's atof: the longest leading floating-point literal, 0.0 if none."""
+  m = re.match(r'\s*[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?'
+               r'|inf(inity)?|nan)', text, re.I)
+  return float(m.group(0)) if m else 0.0
+
+
 def compare(got: np.ndarray, want: np.ndarray, lo: Sequence[int],
-            hi: Sequence[int], threshold: float = 1e-5) -> int:
+            hi: Sequence[int], threshold: Optional[float] = None) -> int:
   """Number of mismatching cells inside box [lo, hi): integers must be equal;
-  floats fail iff (d^2 > t^2) and (d^2 / ref^2 > t^2)."""
+  floats fail iff (d^2 > t^2) and (d^2 / ref^2 > t^2), t = 0.00001 unless the
+  environment says otherwise -- `$THRESHOLD`, read with atof() per compare as
+  the reference's generated host does (frt/host.py:634-637); an explicit
+  `threshold` argument outranks both."""
+  if threshold is None:
+    threshold = 1e-5
+    env = os.environ.get('THRESHOLD')
+    if env is not None:
+      threshold = _atof(env)
   idx = _box_slices(lo, hi, (0,) * len(lo))
   g, w = got[idx], want[idx]
   if np.issubdtype(w.dtype, np.floating):

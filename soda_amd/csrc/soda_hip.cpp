@@ -774,14 +774,35 @@ int plan_launches(const soda_hip_plan_t& plan,
                                (int64_t)fused * cone->reach_hi, lb);
         }
         if (L.record) {
-          // chunks that deliver send rows -- and, below / above them, the only
-          // ones that write the result's ghost rows
+          // `sendable` promises two things to the exchange that is ordered
+          // behind it: the rows the neighbours fetch are complete, and NOTHING
+          // launched later in this run writes the result's ghost rows (the
+          // exchange overwrites them next).  So the boundary holds the chunks
+          // that deliver send rows ...
           if (slab->send_lo > 0) {
             const int64_t v = ceil_div(cone->keep_lo + slab->send_lo - lo, lb);
             if (v > bnd_lo) bnd_lo = v;
           }
           if (slab->send_hi > 0) {
             const int64_t v = floor_div(cone->keep_hi - slab->send_hi - lo, lb);
+            if (v < bnd_hi) bnd_hi = v;
+          }
+          // ... AND every chunk that writes a row outside the kept range, on
+          // either side, whether or not that side sends anything.  With a
+          // symmetric reach the send rule above already covers them (a side
+          // with ghosts is a side that sends); with a one-sided reach (upwind
+          // taps: ghosts above, sends below) it does not, and when the run
+          // also has nothing to wait for (fresh ghosts: the wait rule is off)
+          // the top chunk -- which writes the upper ghost rows -- used to
+          // count as interior and could overwrite the rows the next exchange
+          // had just received (tools/flake_loop.py, round 4: 2 of 400 skewed
+          // trials of the upwind case).
+          if (cone->keep_lo > lo) {
+            const int64_t v = ceil_div(cone->keep_lo - lo, lb);
+            if (v > bnd_lo) bnd_lo = v;
+          }
+          if (cone->keep_hi < hi) {
+            const int64_t v = floor_div(cone->keep_hi - lo, lb);
             if (v < bnd_hi) bnd_hi = v;
           }
         }

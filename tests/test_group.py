@@ -92,6 +92,8 @@ def test_split_passes_keep_clear_of_the_exchange(built, name, extent, fuse,
             assert first >= keep[0] + run.send_lo
           if l['record'] and run.send_hi:
             assert end <= keep[1] - run.send_hi
+          if l['record']:      # behind `sendable` only kept rows are written
+            assert first >= keep[0] and end <= keep[1]
   if iterate > 1 or name == 'blur.soda':
     assert seen_split, 'no pass of any configuration was split'
 
@@ -434,15 +436,28 @@ def test_split_passes_with_a_one_sided_reach(built):
   assert (reach_lo, reach_hi) == (0, 1)
   rows, ghost = extent[-1], 8
   seen = 0
-  for below, above in ((True, True), (False, True), (True, False)):
+  for below, above, exchanged in ((True, True, True), (False, True, True),
+                                  (True, False, True), (True, True, False),
+                                  (False, True, False)):
     g_hi = ghost * reach_hi if above else 0        # ghosts: above only
     keep = (0, rows - g_hi)
-    run = runtime.SlabRun(keep[0], keep[1], reach_lo, reach_hi, 0, g_hi, 0, 0,
-                          1 if g_hi else None, 1)
+    # `exchanged` False: the run opens on fresh ghosts -- nothing to wait for,
+    # no ghost rows named -- but the rows above the kept range are still the
+    # RESULT's ghost rows, which the exchange that follows overwrites: the
+    # chunks that write them must go in front of `sendable` all the same (the
+    # hole tools/flake_loop.py found in round 4: only the side that SENDS
+    # pulled its end chunks into the boundary)
+    run = runtime.SlabRun(keep[0], keep[1], reach_lo, reach_hi, 0,
+                          g_hi if exchanged else 0, 0, 0,
+                          1 if g_hi and exchanged else None, 1)
     run.send_lo = ghost * reach_hi if below else 0   # the slab below fetches
     run.send_hi = 0                                  # nobody above does
     launches = runtime.plan_launches(plan, extent, 8, run)
     assert sum(l['fused_iters'] for l in launches) == 8
+    last = launches[-1]
+    assert last['record']
+    if g_hi:       # the top chunk writes ghost rows: never behind `sendable`
+      assert last['split'] == 0 or last['bnd_hi'] < last['chunks']
     for l in launches:
       if not l['split']:
         continue
@@ -455,6 +470,8 @@ def test_split_passes_with_a_one_sided_reach(built):
           assert end + t * reach_hi <= rows - g_hi
         if l['record'] and run.send_lo:
           assert first >= keep[0] + run.send_lo
+        if l['record']:
+          assert first >= keep[0] and end <= keep[1]
       if l['wait'] and not l['record']:
         assert l['bnd_lo'] == 0          # nothing to wait for at the low end
   assert seen

@@ -243,6 +243,31 @@ def test_compare_rule():
   assert numpy_oracle.compare(b, a, (0, 0), (4, 4)) == 1
 
 
+def test_compare_rule_honours_threshold_from_the_environment(monkeypatch):
+  """`$THRESHOLD` replaces the 1e-5 of the rule, read with atof() as the
+  reference's generated host does (frt/host.py:634-637); integers ignore it."""
+  from oracle import numpy_oracle
+  want = np.full((4, 4), 100.0, np.float32)
+  got = want.copy()
+  got[2, 2] += 0.01                      # rel 1e-4
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 1
+  monkeypatch.setenv('THRESHOLD', '0.001')
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 0
+  monkeypatch.setenv('THRESHOLD', '1e-6')
+  got[1, 1] += 0.0005                    # rel 5e-6: now a mismatch too
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 2
+  monkeypatch.setenv('THRESHOLD', '1e-3 (loose)')       # atof: leading number
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 0
+  monkeypatch.setenv('THRESHOLD', 'none')               # atof: 0.0
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4)) == 2
+  assert numpy_oracle.compare(got, want, (0, 0), (4, 4), threshold=1e-3) == 0
+  a = np.arange(16, dtype=np.uint16).reshape(4, 4)
+  b = a.copy()
+  b[3, 3] += 1
+  monkeypatch.setenv('THRESHOLD', '10')
+  assert numpy_oracle.compare(b, a, (0, 0), (4, 4)) == 1
+
+
 # -- border: preserve (this build's definition; the reference only parses it) --
 @pytest.mark.parametrize('name,iterate,extent', [
     ('jacobi2d.soda', 3, (37, 21)),

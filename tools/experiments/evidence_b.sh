@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence of a round, part B: the other BASELINE configs (durations, PMC
 # traffic), every config on one GPU, the reference corpus, the library's time
-# model against the clock -> gpurun_out/<tag>_*.   usage: tools/evidence_b.sh r02
+# model against the clock -> gpurun_out/<tag>_*.   usage: tools/experiments/evidence_b.sh r02
 set -o pipefail
 tag=${1:-r02}
 out=gpurun_out
