@@ -40,7 +40,7 @@ def add_arguments(parser) -> None:
   parser.add_argument('--hip-backend', action='store_true', dest='hip_backend',
                       help='JIT-build the HIP kernels and run them on the GPU')
   parser.add_argument('--hip-strategy', type=str, dest='hip_strategy',
-                      choices=('auto', 'direct', 'march', 'lds'), default='auto',
+                      choices=('auto', 'direct', 'march', 'lds', 'ldswin'), default='auto',
                       help='kernel family: register-marching wavefront strips '
                       '(2-D / 3-D programs) or the direct kernels')
   parser.add_argument('--hip-fuse', type=int, nargs='*', dest='hip_fuse',

@@ -44,6 +44,8 @@ from soda_amd.codegen.hip.module import (KernelDesc, Module, PassDesc,  # noqa: 
 from soda_amd.codegen.hip.direct import DIRECT_BLOCK, add_direct_pass  # noqa: F401
 from soda_amd.codegen.hip.lds2d import (add_lds2d_pass,  # noqa: F401
                                         lds2d_supported)
+from soda_amd.codegen.hip.ldswin import (add_ldswin_pass,  # noqa: F401
+                                         ldswin_pays, ldswin_supported)
 from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_FUSE_PRESERVE,  # noqa: F401
                                         MAX_SHIFT_TEMPS,
                                         MAX_UNROLL, REG_BUDGET, MarchConfig,
@@ -259,6 +261,25 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     mine, theirs = stencil.iteration_boxes(), other.iteration_boxes()
     return all(mine[o] == theirs[o] for o in stencil.output_names)
 
+  # wide 2-D windows through an LDS row ring (ldswin.py): a whole stage per
+  # thread, so every pointwise local -- the groups of a rebalanced sum included
+  # -- is a sub-expression there.  On request, and by itself where it pays
+  # (contrast: one input, 17 x 17 taps, 393 operations per cell)
+  if opts.strategy in ('auto', 'ldswin') and stencil.dim == 2 and \
+      os.environ.get('SODA_HIP_LDSWIN', '1') != '0':
+    from soda_amd.optimization import pointwise
+    whole = pointwise.inline_pointwise(stencil, fold_groups=True,
+                                       max_ops=1 << 20)
+    if same_boxes(whole) and (
+        (opts.strategy == 'ldswin' and ldswin_supported(whole) is None) or
+        (opts.strategy == 'auto' and ldswin_pays(whole) and
+         (opts.vec is None or opts.vec % 4 == 0))):
+      mod = Module(whole)
+      add_ldswin_pass(mod, chunk=opts.chunk_rows or 64)
+      return mod
+  if opts.strategy == 'ldswin':
+    raise util.SemanticError('ldswin: %s' % (
+        ldswin_supported(stencil) or 'the program does not fold to one stage'))
   if opts.inline and opts.strategy != 'lds':
     from soda_amd.optimization import pointwise
     folded = pointwise.inline_pointwise(stencil)

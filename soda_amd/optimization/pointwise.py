@@ -40,8 +40,14 @@ def _shift(expr: ir.Node, by, params) -> ir.Node:
   return expr.transform(fn)
 
 
-def inline_pointwise(stencil: core.Stencil) -> core.Stencil:
-  """The derived program (a new Stencil), or `stencil` itself."""
+def inline_pointwise(stencil: core.Stencil, fold_groups: bool = False,
+                     max_ops: int = MAX_OPS) -> core.Stencil:
+  """The derived program (a new Stencil), or `stencil` itself.  `fold_groups`:
+  also fold the `cr_var_*` groups of a rebalanced sum -- each becomes the
+  parenthesised, cast sub-expression `T(group)` of the final sum, i.e. the
+  SAME association (a group is summed on its own, rounded to T, then added),
+  only no longer a tensor; for kernel families that evaluate a whole stage per
+  thread (ldswin) and have no use for a register window per group."""
   params = set(stencil.param_names)
   stmts = {s.name: s for s in stencil.local_stmts}
   consumers: Dict[str, List] = {}
@@ -52,11 +58,13 @@ def inline_pointwise(stencil: core.Stencil) -> core.Stencil:
           consumers.setdefault(ref.name, []).append((s, ref))
   fold = {}
   for name, s in stmts.items():
-    if s.let or name.startswith('cr_var_') or name not in consumers:
+    if s.let or name not in consumers:
+      continue
+    if name.startswith('cr_var_') and not fold_groups:
       continue
     if any(ref.idx != s.ref.idx for _, ref in consumers[name]):
       continue
-    if ir.op_count(s.expr) > MAX_OPS:
+    if ir.op_count(s.expr) > max_ops:
       continue
     fold[name] = s
   if not fold:

@@ -455,12 +455,37 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(overlap):
   cfg = out['config']
   assert cfg['exchanges_per_step'] == 2 and cfg['ghost_rows_per_side'] == 24
   assert 'REHEARSAL' in cfg['transport']
+  # the step bench.py checks after its timed region: both ranks' rows gathered
+  # on rank 0, the whole valid box against the C oracle
+  lo, hi = 48, 2048 - 48
+  assert out['parity'] == dict(out['parity'], mismatches=0,
+                               cells=(hi - lo) * (hi - lo))
+  assert out['clock_warm_steps'] >= 10
   if overlap == 'auto':
     trial = cfg['overlap_trial']
     assert 'overlapped_failed' not in trial, trial
     assert trial['overlapped_ms_per_step'] > 0 and trial['serial_ms_per_step'] > 0
   else:
     assert cfg['overlap'] == (overlap == 'on')
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_a_result_check():
+  """bench.py on one GPU (a small grid, the default depth set): the JSON line
+  reports the step it checked against the C oracle after the timed region --
+  every cell of the valid box, no mismatch -- and how long it span the clocks
+  up; a wrong result would also have made it exit non-zero."""
+  import json
+  run = _run_bench('--steps', '3', '--warmup', '1', '--extent', '2048', '1536',
+                   '--iterate', '38', '--no-cpu-baseline', '--no-single-iter',
+                   '--no-rehearsal', '--clock-warm-seconds', '0.05')
+  assert run.returncode == 0, run.stderr[-3000:]
+  out = json.loads([l for l in run.stdout.splitlines()
+                    if l.startswith('{')][-1])
+  assert out['parity']['mismatches'] == 0
+  assert out['parity']['cells'] == (2048 - 76) * (1536 - 76)
+  assert out['clock_warm_steps'] >= 10 and out['value'] > 0
+  assert out['roofline']['kernel'].startswith('jacobi2d_march2d_T')
 
 
 @pytest.mark.gpu

@@ -1029,6 +1029,58 @@ def test_committed_golden_vectors_on_gpu(built, tag, soda, border, strategy):
     assert np.array_equal(got[o][idx], data['out_' + o][idx])
 
 
+WIDE_INT = """kernel: wideint
+burst width: 64
+unroll factor: 2
+iterate: 1
+input int32: a(64, *)
+local int32: s(0, 0) = a(-6, -3) * 3 + a(-2, -1) * 5 - a(0, 0) + a(3, 1) * 7 + a(7, 2)
+output int32: b(0, 0) = s(0, 0) / 3 + a(-5, 2) * a(6, -3) - a(1, 0)
+"""
+
+WIDE_FLOAT = """kernel: widefloat
+burst width: 64
+unroll factor: 2
+iterate: 1
+input float: a(64, *)
+output float: b(1, -1) = (a(-9, -2) + a(12, 0) * 0.25f) * (a(0, 1) - a(3, -4) / (1.5f + a(2, 2) * a(2, 2))) + sqrt(a(10, 3) + 1.0f) + a(-1, -1) * a(11, -4)
+"""
+
+
+@pytest.mark.parametrize('text,extent', [
+    ('contrast.soda', (1024, 200)),
+    ('contrast.soda', (520, 77)),           # a ragged second strip, odd chunks
+    ('contrast.soda', (2052, 131)),
+    ('contrast.soda', (20, 40)),            # narrower than one lane's reach
+    (WIDE_INT, (1028, 150)),                # taps on both sides of the cell
+    (WIDE_INT, (36, 70)),
+    (WIDE_FLOAT, (1540, 99)),               # off-centre store
+])
+def test_wide_windows_through_lds(built, text, extent):
+  """`ldswin` (soda_amd/codegen/hip/ldswin.py): window rows in an LDS ring,
+  8 cells per lane, all lanes valid -- contrast with the reference's rebalanced
+  association (its six groups folded into one stage as cast sub-expressions),
+  windows on both sides of the cell, integer cells, an off-centre store; the
+  family `auto` picks for contrast.  Bit for bit against the C oracle, nothing
+  written outside the valid box."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  st = core.from_file(soda_path(text)) if text.endswith('.soda') else \
+      core.from_text(text)
+  with runtime.Program(st, lower.LowerOptions(strategy='ldswin'),
+                       extent=extent) as prog:
+    assert [p.kind for p in prog.module.passes] == ['ldswin']
+  _check(st, extent, lower.LowerOptions(strategy='ldswin'), oracle='c')
+  if text == 'contrast.soda':
+    with runtime.Program(st, lower.LowerOptions(), extent=extent) as prog:
+      assert [p.kind for p in prog.module.passes] == ['ldswin']
+    # ... and it can be told not to (the 7-stage marching form)
+    with runtime.Program(st, lower.LowerOptions(strategy='march'),
+                         extent=extent) as prog:
+      assert {p.kind for p in prog.module.passes} == {'march2d'}
+    _check(st, extent, lower.LowerOptions(strategy='march'), oracle='c')
+
+
 @pytest.mark.parametrize('name,iterate,opts,extent,border', [
     ('jacobi2d.soda', 24, dict(fuse=(12,)), (2050, 1031), None),   # V=2 rows
     ('jacobi2d.soda', 24, dict(fuse=(12,), pipe=4), (2052, 1031), None),

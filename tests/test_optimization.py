@@ -54,6 +54,29 @@ def test_derived_programs_compute_the_same_tensors(path):
     assert want[o][idx].size and np.array_equal(got[o][idx], want[o][idx]), o
 
 
+def test_groups_of_a_rebalanced_sum_fold_into_one_stage():
+  """pointwise.inline_pointwise(fold_groups=True): contrast's six `cr_var_*`
+  groups become cast sub-expressions of the output -- ONE stage for the ldswin
+  kernels -- with the association unchanged: the CPU oracle gets the same bits
+  from the derived program as from the seven-stage one, and the text is not
+  rebalanced a second time."""
+  from oracle import c_oracle
+  from soda_amd.optimization import pointwise
+  st = core.from_file(soda_path('contrast.soda'))
+  assert len(st.ordered_stages) == 7
+  whole = pointwise.inline_pointwise(st, fold_groups=True, max_ops=1 << 20)
+  assert len(whole.ordered_stages) == 1 and not whole.local_stmts
+  assert whole.iteration_boxes()['output'] == st.iteration_boxes()['output']
+  rng = np.random.default_rng(3)
+  extent = (70, 40)
+  ins = {'input': rng.random(extent[::-1], dtype=np.float32)}
+  want = c_oracle.COracle(st, openmp=False).run(ins)['output']
+  got = c_oracle.COracle(whole, openmp=False).run(ins)['output']
+  lo, hi = st.valid_box(extent)
+  assert hi[0] - lo[0] == 54 and hi[1] - lo[1] == 24
+  assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_pointwise_locals_are_folded():
   """denoise3d (ref tests/src/denoise3d.soda:8-29): ten statements, of which
   six differences, r0 and r1 are only read at the cell being computed."""

@@ -27,6 +27,7 @@ def main():
   ap.add_argument('--no-windows', action='store_true')
   ap.add_argument('--no-inline', action='store_true')
   ap.add_argument('--tile-rows', type=int, default=None)
+  ap.add_argument('--chunk', type=int, default=None)
   ap.add_argument('--reg-budget', type=int, default=None)
   ap.add_argument('--out', default=None)
   args = ap.parse_args()
@@ -46,7 +47,8 @@ def main():
                                  reg_budget=args.reg_budget,
                                  windows=False if args.no_windows else None,
                                  inline=False if args.no_inline else None,
-                                 tile_rows=args.tile_rows),
+                                 tile_rows=args.tile_rows,
+                                 chunk_rows=args.chunk),
           extent=extent)
     except Exception as e:   # noqa
       print(json.dumps(dict(program=name, error=str(e)[:200])), flush=True)
