@@ -489,6 +489,34 @@ def test_bench_line_carries_a_result_check():
 
 
 @pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+  """The most of bench.py's RCCL path one GPU can execute: a process group of
+  ONE rank on the nccl backend (SODA_BENCH_FORCE_DIST) -- RCCL initialises, and
+  the barrier and the MAX all-reduces around the clock-warm windows and the
+  timed region really run through it.  (Send / receive between two devices is
+  what remains for the driver's multi-GPU run.)"""
+  import json
+  import subprocess
+  import sys
+  env = dict(os.environ)
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    env.pop(k, None)
+  env.update(SODA_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1',
+             MASTER_PORT=str(_free_port()))
+  run = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3',
+       '--warmup', '1', '--extent', '2048', '1024', '--iterate', '26',
+       '--no-cpu-baseline', '--no-single-iter', '--no-rehearsal',
+       '--clock-warm-seconds', '0.05'],
+      capture_output=True, text=True, env=env, timeout=600)
+  assert run.returncode == 0, run.stderr[-3000:]
+  out = json.loads([l for l in run.stdout.splitlines()
+                    if l.startswith('{')][-1])
+  assert out['rccl_world'] == 1 and out['n_gpus'] == 1
+  assert out['parity']['mismatches'] == 0 and out['clock_warm_steps'] >= 10
+
+
+@pytest.mark.gpu
 def test_bench_launcher_on_the_gpu_box():
   """On the GPU box: with two or more GPUs the self-launched 2-rank run must
   come back with one JSON line from rank 0 and `rccl_world` = 2 (the RCCL

@@ -5,7 +5,8 @@ generic generator (tests/fuzz.py program) and the window generator
 bit; `group`: the same programs cut into virtual slabs (group_scan).
 `options`: random backend knobs on larger grids (options_scan).
 `wire`: behind the reference host's stream format (wire_scan).
-Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire FIRST LAST"""
+`deep`: 8-26 iterations at fusion depths up to 13 (deep_scan).
+Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire|deep FIRST LAST"""
 import os
 import sys
 import time
@@ -324,7 +325,100 @@ def wire_scan(first, last):
   return 1 if failed else 0
 
 
+def deep_scan(first, last):
+  """Deep temporal blocking on random programs (round 4: the scans above fuse
+  at most 3 iterations, bench.py fuses 13): iterable 2-D programs of the plain
+  and the independent-nest generators run 8-26 iterations with fusion depths
+  drawn from {13, 12, 8, 4} (depths whose registers do not fit are dropped by
+  the lowering) on grids of several strips and chunks, half of them with
+  `border: preserve`; against the C oracle AND, for the nest programs, against
+  their own C++ nests."""
+  import fuzz
+  import fuzz_nest
+  from oracle import c_oracle
+  from soda_amd import core, runtime, util
+  from soda_amd.codegen.hip import lower
+  ran = failed = refused = 0
+  t0 = time.time()
+  for seed in range(first, last):
+    rng = np.random.default_rng(seed + 53000)
+    nest = None
+    if rng.random() < 0.5:
+      nest, _ = fuzz_nest.program(seed, 'plain')
+      text, dim, iterable = nest.soda_text(), nest.dim, \
+          len(nest.inputs) == len(nest.outputs) and \
+          [t for _, t in nest.inputs] == [s.typ for s in nest.outputs]
+    else:
+      text, dim, _ = fuzz.program(seed)
+      iterable = None
+    if dim != 2:
+      continue
+    iterate = int(rng.choice([8, 9, 12, 13, 16, 26]))
+    border = 'preserve' if rng.random() < 0.5 and nest is None else None
+    text = '\n'.join('iterate: %d' % iterate if l.startswith('iterate:') else l
+                     for l in text.splitlines()) + '\n'
+    try:
+      stencil = core.from_text(text, **({'border': border} if border else {}))
+      if border:
+        stencil.check_preserve()
+    except util.SodaError:
+      continue                    # not iterable
+    if iterable is False:
+      continue
+    extent = (int(rng.choice([520, 777, 1100])), int(rng.integers(150, 420)))
+    lo, hi = stencil.valid_box(extent)
+    if not border and not all(h > l + 8 for l, h in zip(lo, hi)):
+      continue
+    depths = [t for t in (13, 12, 8, 4) if rng.random() < 0.6] or [13]
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    kw = dict(fuse=tuple(depths), chunk_rows=pick([None, None, 40, 64]),
+              lane_shift=pick([None, None, 'dpp', 'mixh']))
+    if nest is not None:
+      nest.iterate = iterate
+      ins = fuzz_nest.inputs_for(nest, extent, seed)
+    else:
+      ins = fuzz.inputs_for(stencil, extent, seed)
+    what = 'seed %d %s iterate %d%s extent %s %s' % (
+        seed, 'nest' if nest else 'plain', iterate,
+        ' preserve' if border else '', extent, kw)
+    try:
+      with runtime.Program(stencil, lower.LowerOptions(**kw),
+                           extent=extent) as prog:
+        got = prog.run(ins)
+        fused = max(p.fused_iters for p in prog.module.passes)
+    except (util.SodaError, ValueError) as e:
+      refused += 1
+      print('%s: refused: %s' % (what, str(e)[:200]), flush=True)
+      continue
+    want = c_oracle.COracle(stencil).run(ins)
+    own = nest.run(ins, extent) if nest is not None else None
+    ran += 1
+    for o in stencil.output_names:
+      if border:
+        g, w = got[o], want[o]
+      else:
+        lo, hi = stencil.valid_box(extent, o)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+        g, w = got[o][idx], want[o][idx]
+      bad = not np.array_equal(g, w, equal_nan=True)
+      if own is not None and not np.array_equal(got[o], own[o],
+                                                equal_nan=True):
+        bad = True
+      if bad:
+        failed += 1
+        print('%s (deepest pass %d) output %s: %d cells differ\n%s' %
+              (what, fused, o, int((g != w).sum()), text), flush=True)
+    if ran % 10 == 0:
+      print('... %d programs, %d failures, %d refused, %.0f s' %
+            (ran, failed, refused, time.time() - t0), flush=True)
+  print('deep seeds [%d, %d): %d programs run, %d refused, %d failures' %
+        (first, last, ran, refused, failed))
+  return 1 if failed else 0
+
+
 if __name__ == '__main__':
+  if sys.argv[1] == 'deep':
+    sys.exit(deep_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'wire':
     sys.exit(wire_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'options':     # optional 4th argument: only programs containing it
