@@ -12,14 +12,15 @@ the L1 is the bound, 698 us).
 
 Here the window rows live in LDS, written once per block and row:
 
-  * a block is 4 waves; wave w computes output row y + w of a 4-row step, lane
-    l the 8 cells x0 + 8 l ... + 7: ALL 64 lanes valid, no lane ever shifts;
-  * LDS holds a ring of `window height + 7` input rows of 512 + window width
+  * a block is 8 (or 4) waves; wave w computes output row y + w of an 8-row
+    step, lane l the 8 cells x0 + 8 l ... + 7: ALL 64 lanes valid, no lane ever
+    shifts;
+  * LDS holds a ring of `window height + 15` input rows of 512 + window width
     cells (rounded to 16 bytes).  A step reads, per thread and window row, the
     32 + window-width bytes its 8 cells tap with `ds_read_b128`s (consecutive
     lanes 32 bytes apart: conflict-free) -- 6 reads per row for contrast, shared
     by 8 cells, against 85 texture loads per 4 cells in `direct`;
-  * while a step computes, every wave fetches ONE of the next four input rows
+  * while a step computes, every wave fetches ONE of the next step's input rows
     from global memory into registers (coalesced 16-byte loads, 1 KiB per
     instruction) and files it in the ring slot that went dead a step ago; one
     barrier per step orders both directions;
@@ -38,7 +39,7 @@ from soda_amd import core, ir, util
 from soda_amd.codegen.hip.module import KernelDesc, Module, PassDesc
 
 V = 8                   # cells per lane
-STEP = 4                # rows per step = waves per block
+STEP = 4                # rows per step = waves per block (the fallback)
 WIDTH = 64 * V          # columns per block
 MIN_OPS = 96            # below this a program is not compute-bound enough
 MIN_SPAN = 5            # window cells along dimension 0 beyond which lanes are
@@ -77,7 +78,20 @@ def ldswin_pays(stencil: core.Stencil) -> bool:
   return span >= MIN_SPAN and work >= MIN_OPS and stencil.iterate == 1
 
 
-def add_ldswin_pass(mod: Module, chunk: int = CHUNK) -> PassDesc:
+def add_ldswin_pass(mod: Module, chunk: int = CHUNK,
+                    step: Optional[int] = None) -> PassDesc:
+  """`step` rows per step = waves per block; None: 8 where the ring of window
+  height + 15 rows fits 80 KB of LDS (two blocks, four waves per SIMD), else 4.
+  contrast 8192^2 (profiles/r04_contrast2.jsonl, us): 8 rows 512-524, 4 rows
+  533-544, 6 rows 685-712 (six waves do not spread over four SIMDs), 2 rows
+  739-936."""
+  if step is None:
+    try:
+      return add_ldswin_pass(mod, chunk, 8)
+    except util.SemanticError as e:
+      if 'too tall' not in str(e):
+        raise
+      return add_ldswin_pass(mod, chunk, STEP)
   st = mod.stencil
   why = ldswin_supported(st)
   if why:
@@ -101,21 +115,21 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK) -> PassDesc:
   if halo > 64 or klo < -32:
     raise util.SemanticError('ldswin: window too wide')
   pitch = nquad * 4 + 4                        # cells; +16 B keeps rows apart
-  live = wy + STEP                             # rows a step reads
-  ring = live + STEP                           # + the rows it files
+  live = wy + step                             # rows a step reads
+  ring = live + step                           # + the rows it files
   lds_bytes = ring * pitch * 4
-  if lds_bytes > 64 * 1024:
+  if lds_bytes > 80 * 1024:      # two blocks per CU at least
     raise util.SemanticError('ldswin: window too tall for LDS')
   frag = (khi - klo + 1) * 4                   # cells a thread reads per row
-  name = '%s_ldswin_V%d_R%d_C%d' % (st.app_name, V, ring, chunk)
+  name = '%s_ldswin_V%d_S%d_R%d_C%d' % (st.app_name, V, step, ring, chunk)
   L: List[str] = []
   w = L.append
   w('// ldswin: %d x %d cells per step and block, ring of %d rows x %d cells in '
     'LDS (%d bytes); window x %d..%d, y %d..%d' %
-    (WIDTH, STEP, ring, pitch, lds_bytes, xl, xh, yl, yh))
+    (WIDTH, step, ring, pitch, lds_bytes, xl, xh, yl, yh))
   w('// stage `%s`: %s' % (stage.name, ' '.join(str(stage.stmt).split())[:300]))
   w('extern "C" __global__ void __launch_bounds__(%d) %s(soda_hip_kargs_t a) {'
-    % (64 * STEP, name))
+    % (64 * step, name))
   w('  __shared__ __attribute__((aligned(16))) %s ring[%d * %d];' %
     (ct_in, ring, pitch))
   w('  const int lane = (int)(threadIdx.x & 63u);')
@@ -159,16 +173,16 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK) -> PassDesc:
   w('  // ring slot of input row r: (r - first row) mod %d, kept incrementally'
     % ring)
   w('  const int r0 = ybeg + (%d);      // first input row of the chunk' % yl)
-  w('  for (int i = wave; i < %d; i += %d) {' % (live, STEP))
+  w('  for (int i = wave; i < %d; i += %d) {' % (live, step))
   w('    %s q[%d][4];' % (ct_in, nload))
   w('    fetch(r0 + i, q);')
   w('    file(i, q);')
   w('  }')
   w('  int base = 0;                    // slot of the step\'s first input row')
   w('  const int xc = x0 + lane * %d;' % V)
-  w('  for (int y = ybeg; y < yend; y += %d) {' % STEP)
+  w('  for (int y = ybeg; y < yend; y += %d) {' % step)
   w('    __syncthreads();')
-  w('    // the next %d rows travel while this step computes' % STEP)
+  w('    // the next %d rows travel while this step computes' % step)
   w('    %s nq[%d][4];' % (ct_in, nload))
   w('    fetch(y + (%d) + %d + wave, nq);' % (yl, live))
   w('    const int yo = y + wave;')
@@ -203,6 +217,10 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK) -> PassDesc:
     counter[0] += 1
     return 'v%d' % counter[0]
 
+  # (Literal operands make half of the step's instructions 8 bytes long; the
+  # same constants held in registers -- 15 KB of code instead of 20 -- ran 5 %
+  # SLOWER, 118 VGPRs: the step is not bound by instruction fetch,
+  # profiles/r04_contrast3.jsonl.)
   _, results = ir.c_statements(stage.stmt.expr, [mk_load(e) for e in range(V)],
                                fresh, stmts=body)
   L.extend('      ' + x for x in body)
@@ -225,11 +243,11 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK) -> PassDesc:
   w('    // file the fetched rows where the rows this step read first went dead')
   w('    { int s = base + %d + wave; if (s >= %d) s -= %d; file(s, nq); }' %
     (live, ring, ring))
-  w('    base += %d; if (base >= %d) base -= %d;' % (STEP, ring, ring))
+  w('    base += %d; if (base >= %d) base -= %d;' % (step, ring, ring))
   w('  }')
   w('}')
   idx = mod.add_kernel(
-      KernelDesc(name, (64 * STEP, 1, 1), (WIDTH, chunk), lds_bytes=0,
+      KernelDesc(name, (64 * step, 1, 1), (WIDTH, chunk), lds_bytes=0,
                  note='ldswin', tune=dict(vec=4)), '\n'.join(L) + '\n')
   p = PassDesc(1, [idx], 'ldswin',
                dict(bytes_per_cell_min=8, lds_bytes=lds_bytes))

@@ -275,7 +275,8 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
         (opts.strategy == 'auto' and ldswin_pays(whole) and
          (opts.vec is None or opts.vec % 4 == 0))):
       mod = Module(whole)
-      add_ldswin_pass(mod, chunk=opts.chunk_rows or 64)
+      add_ldswin_pass(mod, chunk=opts.chunk_rows or 64,
+                      step=opts.waves_y if opts.waves_y > 1 else None)
       return mod
   if opts.strategy == 'ldswin':
     raise util.SemanticError('ldswin: %s' % (

@@ -1071,6 +1071,9 @@ def test_wide_windows_through_lds(built, text, extent):
                        extent=extent) as prog:
     assert [p.kind for p in prog.module.passes] == ['ldswin']
   _check(st, extent, lower.LowerOptions(strategy='ldswin'), oracle='c')
+  # eight rows per step (eight waves per block, a 32-row ring)
+  _check(st, extent, lower.LowerOptions(strategy='ldswin', waves_y=8,
+                                        chunk_rows=40), oracle='c')
   if text == 'contrast.soda':
     with runtime.Program(st, lower.LowerOptions(), extent=extent) as prog:
       assert [p.kind for p in prog.module.passes] == ['ldswin']

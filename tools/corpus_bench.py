@@ -28,6 +28,7 @@ def main():
   ap.add_argument('--no-inline', action='store_true')
   ap.add_argument('--tile-rows', type=int, default=None)
   ap.add_argument('--chunk', type=int, default=None)
+  ap.add_argument('--waves-y', type=int, default=1)
   ap.add_argument('--reg-budget', type=int, default=None)
   ap.add_argument('--out', default=None)
   args = ap.parse_args()
@@ -48,7 +49,7 @@ def main():
                                  windows=False if args.no_windows else None,
                                  inline=False if args.no_inline else None,
                                  tile_rows=args.tile_rows,
-                                 chunk_rows=args.chunk),
+                                 chunk_rows=args.chunk, waves_y=args.waves_y),
           extent=extent)
     except Exception as e:   # noqa
       print(json.dumps(dict(program=name, error=str(e)[:200])), flush=True)

@@ -46,7 +46,7 @@ def main():
   valu = read_counters(sys.argv[5]) if len(sys.argv) > 5 else {}
   result = {}
   for name, st in stats.items():
-    if 'march' not in name and 'direct' not in name and 'copy' not in name:
+    if not any(w in name for w in ('march', 'direct', 'copy', 'ldswin', 'lds2d')):
       continue
     entry = dict(st)
     f = fetch.get(name, {}).get('FETCH_SIZE')
