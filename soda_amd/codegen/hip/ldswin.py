@@ -54,6 +54,8 @@ def ldswin_supported(stencil: core.Stencil) -> Optional[str]:
       len(stencil.output_names) != 1:
     return 'ldswin handles single-stage, single-input programs'
   stage = stencil.ordered_stages[0]
+  if stencil.input_names[0] not in stage.taps:
+    return 'ldswin: the stage reads no tensor'
   if stage.stmt.let:
     return 'ldswin does not handle let variables'
   if stencil.param_stmts:

@@ -50,6 +50,35 @@ def test_generator_covers_the_language():
   assert len({fuzz.program(s)[1] for s in GPU_SEEDS}) == 3   # 1-, 2-, 3-D
 
 
+def test_every_gpu_seed_lowers_without_a_gpu():
+  """The lowering of every program the GPU tests run -- family choice, program
+  rewrites, kernel text -- executed here on the CPU: a crash in a code path the
+  choice of family walks for EVERY program (round 4: `ldswin_pays` on a stage
+  that reads no tensor) must not wait for the GPU box to be found."""
+  import fuzz_nest
+  from soda_amd.codegen.hip import lower
+  texts = [fuzz.program(s)[0] for s in GPU_SEEDS]
+  texts += [fuzz.program(s, rich=True)[0] for s in range(0, 60)]
+  texts += [fuzz.window_program(s)[0] for s in range(0, 45)]
+  texts += [fuzz_nest.program(s, f)[0].soda_text()
+            for f in ('plain', 'rich', 'window') for s in range(0, 30)]
+  lowered = 0
+  for text in texts:
+    try:
+      stencil = core.from_text(text)
+    except util.SodaError:
+      continue
+    for strategy in ('auto', 'direct'):
+      try:
+        mod = lower.lower(stencil, lower.LowerOptions(strategy=strategy,
+                                                      fuse=(2,), peel=0))
+      except util.SodaError:      # a refusal is fine, anything else is not
+        continue
+      assert mod.kernels and mod.passes
+      lowered += 1
+  assert lowered > 400
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('seed', GPU_SEEDS)
 def test_gpu_matches_oracle(built, seed):
