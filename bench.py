@@ -617,6 +617,10 @@ def main():
       follows whatever happened here (a rank that left the sequence would
       leave the others in a barrier nobody completes)."""
       try:
+        # (test hook: every rank fails its overlapped steps before touching a
+        # peer -- what a refused argument or a missing symbol looks like)
+        if mode['overlap'] and os.environ.get('SODA_BENCH_INJECT_OVERLAP_FAILURE'):
+          raise RuntimeError('injected failure of the overlapped step')
         for _ in range(n_steps):
           one_step()
         torch.cuda.synchronize()
@@ -624,6 +628,11 @@ def main():
       except Exception as e:          # noqa: BLE001
         return '%s: %s' % (type(e).__name__, str(e)[:200])
 
+    # (What this cannot cure: ONE rank failing in the middle of an exchange --
+    # its peers then wait for a message inside one_step() and never reach the
+    # reduction; RCCL's watchdog ends such a job.  Failures every rank sees at
+    # the same point -- the realistic kind for a code path that has never run
+    # on real links -- fall back to the serial exchange cleanly.)
     def any_rank(err):
       t = torch.tensor([1.0 if err else 0.0], device=dev, dtype=torch.float64)
       tdist.all_reduce(t, op=tdist.ReduceOp.MAX)

@@ -724,8 +724,10 @@ def select_shape(stencil: core.Stencil, opts: 'lower.LowerOptions',
   243-247 registers without spilling and run in 60-67 us
   (profiles/r03_windows_sweep.jsonl).  So, like select_peel, ask the compiler:
   the widest shape above the ladder's choice whose compiled one-iteration
-  kernel needs at most 256 registers and no scratch.  Trials are JIT-compiled
-  (no GPU) and remembered in the kernel cache."""
+  kernel fits the register file -- at most 512 registers per lane, accumulation
+  registers included: one wave per SIMD (xcorr at 8 cells per lane: 314, still
+  faster than 4 cells per lane at 160) -- and needs no scratch.  Trials are
+  JIT-compiled (no GPU) and remembered in the kernel cache."""
   import copy
   import json
   if opts.strategy not in ('auto', 'march') or stencil.iterate > 1:
@@ -1176,7 +1178,14 @@ class Group:
       if grown == local:
         break
       local = grown
-    desc.exchange_every = every.value
+    # The model's interval shaped the kernels.  With calibrate=True and no
+    # interval of the caller's, create is handed 0 so that the LIBRARY times
+    # the model's best candidates on a middle slab's GPU and lets the clock
+    # pick (soda_hip_group_create: exchange_every == 0 && GROUP_CALIBRATE);
+    # the kernels run on any extent, only their peel / chunk choices were made
+    # for the model's one.
+    desc.exchange_every = 0 if (calibrate and exchange_every == 0) else \
+        every.value
     self.exchange_every = every.value
     self._handle = ctypes.c_void_p()
     check(

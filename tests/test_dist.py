@@ -470,6 +470,39 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(overlap):
 
 
 @pytest.mark.gpu
+def test_bench_overlap_trial_survives_a_failing_overlapped_way():
+  """`--overlap auto`: when the overlapped step fails on every rank (injected:
+  the first thing a never-executed path would do on real links), all ranks go
+  through the same collectives, agree on the serial exchange and the run
+  completes -- checked result included."""
+  import json
+  import subprocess
+  import sys
+  env = dict(os.environ)
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    env.pop(k, None)
+  env.update(SODA_BENCH_ONE_GPU='1', SODA_BENCH_BACKEND='gloo',
+             SODA_BENCH_INJECT_OVERLAP_FAILURE='1')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'),
+         '--gpus', '2', '--steps', '2', '--warmup', '1', '--extent', '2048',
+         '2048', '--iterate', '48', '--fuse', '12', '4', '--exchange-every',
+         '24', '--overlap', 'auto', '--no-cpu-baseline', '--no-single-iter',
+         '--clock-warm-seconds', '0.05']
+  run = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=600)
+  assert run.returncode == 0, run.stderr[-3000:]
+  out = json.loads([l for l in run.stdout.splitlines()
+                    if l.startswith('{')][-1])
+  trial = out['config']['overlap_trial']
+  assert 'injected failure' in trial['overlapped_failed']
+  assert trial['overlapped_ms_per_step'] is None
+  assert trial['serial_ms_per_step'] > 0 and out['config']['overlap'] is False
+  assert out['parity']['mismatches'] == 0
+
+
+@pytest.mark.gpu
 def test_bench_line_carries_a_result_check():
   """bench.py on one GPU (a small grid, the default depth set): the JSON line
   reports the step it checked against the C oracle after the timed region --

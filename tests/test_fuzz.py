@@ -127,7 +127,7 @@ def test_oracles_agree_with_preserved_border(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('seed', GPU_SEEDS)
+@pytest.mark.parametrize('seed', range(0, 45))
 def test_gpu_matches_oracle_with_preserved_border(built, seed):
   from soda_amd import runtime
   from soda_amd.codegen.hip import lower
@@ -272,7 +272,7 @@ def test_gpu_matches_oracle_on_window_programs(built, seed):
 
 # -- the wider operator set (tests/fuzz.py _expr_rich) ------------------------
 RICH_CPU_SEEDS = range(0, 40)
-RICH_GPU_SEEDS = range(0, 60)
+RICH_GPU_SEEDS = range(0, 45)
 
 
 def _build_rich(seed):
