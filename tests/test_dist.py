@@ -457,7 +457,8 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(overlap):
   assert 'REHEARSAL' in cfg['transport']
   # the step bench.py checks after its timed region: both ranks' rows gathered
   # on rank 0, the whole valid box against the C oracle
-  lo, hi = 48, 2048 - 48
+  # (two chained steps: the second opens with the exchange)
+  lo, hi = 96, 2048 - 96
   assert out['parity'] == dict(out['parity'], mismatches=0,
                                cells=(hi - lo) * (hi - lo))
   assert out['clock_warm_steps'] >= 10
