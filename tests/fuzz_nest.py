@@ -506,9 +506,11 @@ def _arith(rng, leaf, is_float, depth, rich, to_int):
 
 
 def program(seed, family='plain'):
-  """(Program, extent) for `family` in plain / rich / window."""
+  """(Program, extent) for `family` in plain / rich / window / wide."""
   if family == 'window':
     return _window_program(seed)
+  if family == 'wide':
+    return _wide_program(seed)
   rich = family == 'rich'
   rng = np.random.default_rng(seed + (881000 if rich else 880000))
   dim = int(rng.choice([1, 2, 2, 2, 3]))
@@ -639,6 +641,66 @@ def _window_program(seed):
   else:
     extent = (int(rng2.choice([64, 130, 260])), int(rng2.integers(24, 40)),
               int(rng2.integers(30, 60)))
+  return prog, extent
+
+
+def _wide_program(seed):
+  """One input of 4-byte cells, one or two statements (a local read at the
+  consumer's own cell, or none), 12-40 taps spread over a window up to 21 cells
+  wide and 9 rows tall on both sides of the cell, mixed-precedence arithmetic
+  with literals: the shape the `ldswin` kernels serve (an LDS row ring)."""
+  rng = np.random.default_rng(seed + 883000)
+  typ = ['float', 'float', 'int32'][int(rng.integers(3))]
+  is_float = typ == 'float'
+  xl, xh = -int(rng.integers(0, 11)), int(rng.integers(1, 11))
+  yl, yh = -int(rng.integers(0, 5)), int(rng.integers(0, 5))
+  inputs = [('a', typ)]
+
+  def tap(name='a'):
+    return Ref(name, (int(rng.integers(xl, xh + 1)),
+                      int(rng.integers(yl, yh + 1))), typ)
+
+  def lit():
+    return Lit('%.3ff' % rng.uniform(0.05, 1.5) if is_float
+               else str(int(rng.integers(1, 9))))
+
+  def chain(n, leaf):
+    node = leaf()
+    for _ in range(n):
+      r = rng.random()
+      rhs = leaf()
+      if r < 0.5:
+        rhs = Bin('*', rhs, lit())
+      elif r < 0.6:
+        rhs = Bin('*', rhs, leaf())
+      elif r < 0.65 and is_float:
+        d = leaf()
+        rhs = Bin('/', rhs, Bin('+', Lit('1.5f'), Bin('*', d, d)))
+      elif r < 0.7:
+        rhs = Call(['min', 'max'][int(rng.integers(2))],
+                   _same_type([rhs, leaf()]))
+      node = Bin(['+', '-', '+'][int(rng.integers(3))], node, rhs)
+    return node
+
+  stmts = []
+  store = _idx(rng, 2, 1) if rng.random() < 0.3 else (0, 0)
+  if rng.random() < 0.5:
+    lstore = _idx(rng, 2, 1) if rng.random() < 0.3 else (0, 0)
+    stmts.append(Stmt('local', typ, 's', lstore,
+                      chain(int(rng.integers(6, 20)), tap)))
+    # the consumer reads the local at its own store index only: the local is
+    # "pointwise" (what it computed for the consumer's base cell)
+    sref = lambda: Ref('s', lstore, typ)
+    expr = Bin('+', Bin('*', sref(), lit()),
+               chain(int(rng.integers(6, 20)), tap))
+    if rng.random() < 0.5:
+      expr = Bin('-', expr, sref())
+  else:
+    expr = chain(int(rng.integers(12, 40)), tap)
+  stmts.append(Stmt('output', typ, 'b', store, expr))
+  prog = Program('widenest%d' % seed, 2, 1, inputs, stmts)
+  rng2 = np.random.default_rng(seed + 884000)
+  extent = (int(rng2.choice([36, 520, 1028, 1540])), int(rng2.integers(40, 160)))
   return prog, extent
 
 
