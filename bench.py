@@ -291,6 +291,54 @@ def group_main(args):
   }))
 
 
+class HostStagedP2P:
+  """(REHEARSAL transports only.)  soda_amd.dist orders a halo exchange on a
+  HIP stream, which is what RCCL's send / recv do.  gloo does not: handed a
+  device tensor, its send / recv threads read and write the GPU's memory
+  through the CPU's mapping of it whenever they get to it -- unordered against
+  every stream, past the GPU's caches (round 4: the result check this file
+  gained caught 2359 wrong cells in one of four two-rank rehearsals).  For any
+  backend but nccl the point-to-point calls therefore go through host buffers:
+  a send copies its rows out behind the current stream first, a receive lands
+  in a host buffer and is copied in on the current stream by wait().  The
+  collectives (all_reduce, broadcast, all_gather, barrier) are gloo's own,
+  which do stage device tensors correctly."""
+  isend, irecv = 'isend', 'irecv'
+
+  class _Req:
+
+    def __init__(self, work, tensor=None, host=None):
+      self.work, self.tensor, self.host = work, tensor, host
+
+    def wait(self):
+      self.work.wait()
+      if self.tensor is not None:
+        self.tensor.copy_(self.host)       # on the caller's current stream
+
+  def __init__(self, tdist):
+    self._t = tdist
+
+  def __getattr__(self, name):
+    return getattr(self._t, name)
+
+  @staticmethod
+  def P2POp(op, tensor, peer, group=None):
+    return (op, tensor, peer, group)
+
+  def batch_isend_irecv(self, ops):
+    import torch
+    reqs = []
+    for op, tensor, peer, group in ops:     # sends first: they never block
+      if op == self.isend:
+        host = tensor.cpu()                 # behind the current stream
+        reqs.append(self._Req(self._t.isend(host, peer, group), host=host))
+    for op, tensor, peer, group in ops:
+      if op == self.irecv:
+        host = torch.empty(tensor.shape, dtype=tensor.dtype, device='cpu')
+        reqs.append(self._Req(self._t.irecv(host, peer, group), tensor, host))
+    return reqs
+
+
 def launch_ranks(args) -> int:
   """`bench.py --gpus N` started by hand (no WORLD_SIZE in the environment):
   this process becomes the launcher.  It touches no GPU (counting devices does
@@ -360,6 +408,7 @@ def main():
       tdist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     elif backend != 'nccl':
       tdist.init_process_group(backend)
+      tdist = HostStagedP2P(tdist)     # (a rehearsal: see the class)
     else:
       tdist.init_process_group('nccl', device_id=dev)
     rccl_world = tdist.get_world_size()

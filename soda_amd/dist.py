@@ -20,6 +20,13 @@ the single-GPU result: every cell runs the same arithmetic.
 The local compute engine is injected (`step(dst, src, local_extent, iters)`):
 on GPUs it is `runtime.Program.run_device`; the CPU tests drive the same
 decomposition/exchange code over gloo with a CPU engine.
+
+The transport (`dist_module`: torch.distributed or a stand-in) must order a
+message on a DEVICE tensor against the HIP stream that is current when it is
+posted -- RCCL (backend "nccl") does.  gloo does not: its send / recv threads
+touch the GPU's memory through the CPU whenever they get to it, so a rehearsal
+over gloo must stage device tensors through host buffers itself
+(bench.py HostStagedP2P, tests/test_dist.py _gpu_worker).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
 
