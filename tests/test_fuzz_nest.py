@@ -12,7 +12,7 @@ import fuzz_nest
 
 FAMILIES = ('plain', 'rich', 'window')
 CPU_SEEDS = range(0, 60)
-GPU_SEEDS = range(0, 30)
+GPU_SEEDS = range(0, 25)
 
 
 def _same(a, b):
