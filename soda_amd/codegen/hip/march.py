@@ -1260,7 +1260,13 @@ class _MarchKernel:
       self.w('      if (%s) {  // wave-uniform' % guard)
       self.L.extend(early)
     elif early:
-      # place them in front of the previous stage's block of this tick
+      # place them in front of the previous stage's block of this tick.
+      # (The compiler sinks each to one stage's arithmetic ahead of its use,
+      # one swizzle in flight at a time.  Round 4 pinned all 13 of a T=13 step
+      # at the head of the step behind a scheduling barrier -- 13 in flight,
+      # 162 VGPRs, bit-exact -- and gained nothing: T12 145-146 us either way,
+      # T13 170 against 156-161, profiles/r04_early_*.json.  The swizzles'
+      # latency is not what the step waits for.)
       self.L[self._stage_mark:self._stage_mark] = early
     if n.keep is not None:
       # border: preserve -- cells one iteration cannot compute keep the value
