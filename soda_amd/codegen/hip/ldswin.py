@@ -116,7 +116,19 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK,
   halo = nquad - 128                           # quads beyond the 128 own ones
   if halo > 64 or klo < -32:
     raise util.SemanticError('ldswin: window too wide')
-  pitch = nquad * 4 + 4                        # cells; +16 B keeps rows apart
+  # A ring row keeps its even quads in one region and its odd quads in another
+  # (`odd0` cells further on): lane l reads quads 2 l + k, so consecutive lanes
+  # read consecutive 16-byte quads of ONE region -- conflict-free, where the
+  # plain layout had lanes 32 bytes apart and two lanes of every 16 on the
+  # same banks (round 4, SQ counters of the plain layout: 4.7e7 of 9.9e7 LDS
+  # cycles were bank conflicts).  The odd region starts 128 bytes off a
+  # 256-byte boundary, so a filing instruction's even and odd lanes (which
+  # write the two regions at equal offsets) miss each other's banks as well.
+  half = (nquad + 1) // 2                      # quads per region
+  odd0 = half * 4                              # cells
+  while (odd0 * 4) % 256 != 128:
+    odd0 += 4
+  pitch = odd0 + half * 4                      # cells
   live = wy + step                             # rows a step reads
   ring = live + step                           # + the rows it files
   lds_bytes = ring * pitch * 4
@@ -168,8 +180,9 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK,
   w('  auto file = [&](int slot, const %s (&q)[%d][4]) {' % (ct_in, nload))
   for f in range(nload):
     guard = 'if (lane < %d) ' % halo if f == 2 else ''
-    w('    %ssoda_store_frag<%s, 4>(&ring[slot * %d + 4 * (%d + lane)], q[%d]);'
-      % (guard, ct_in, pitch, 64 * f, f))
+    # quad 64 f + lane of the row: region by its parity, place by its half
+    w('    %ssoda_store_frag<%s, 4>(&ring[slot * %d + (lane & 1) * %d + '
+      '4 * ((%d + lane) >> 1)], q[%d]);' % (guard, ct_in, pitch, odd0, 64 * f, f))
   w('  };')
   # ---- prologue: the rows the first step reads ------------------------------
   w('  // ring slot of input row r: (r - first row) mod %d, kept incrementally'
@@ -202,11 +215,12 @@ def add_ldswin_pass(mod: Module, chunk: int = CHUNK,
         body.append('%s %s[%d];' % (ct_in, var, frag))
         body.append('{ int s = base + wave + (%d); if (s >= %d) s -= %d;' %
                     (dy - yl, ring, ring))
-        body.append('  const %s* p = &ring[s * %d + lane * %d];' %
-                    (ct_in, pitch, V))
-        for k in range(khi - klo + 1):
+        body.append('  const %s* p = &ring[s * %d + lane * 4];' %
+                    (ct_in, pitch))
+        for k in range(khi - klo + 1):    # quad 2 lane + k of the row
           body.append('  soda_load_frag<%s, 4, false>(*(%s(*)[4])&%s[%d], '
-                      'p + %d);' % (ct_in, ct_in, var, 4 * k, 4 * k))
+                      'p + %d);' % (ct_in, ct_in, var, 4 * k,
+                                    (odd0 if k % 2 else 0) + 4 * (k // 2)))
         body.append('}')
         rows[dy] = var
       # cell e of the lane taps column 8 l + e + dx = fragment cell e + dx - 4 klo
