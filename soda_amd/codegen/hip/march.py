@@ -26,6 +26,7 @@ class _Node:
     self.it = it
     self.parents: Dict[str, '_Node'] = {}   # DSL name -> node
     self.delay = 0              # ticks between issue of input plane t and plane t here
+    self.first_use = None       # age of the youngest plane any child reads
     self.window = 1             # planes (rows in 2-D) kept
     self.slots = 1              # window padded to a divisor of the unroll
     self.margin = [0, 0]        # invalid cells at the low/high end of a strip
@@ -345,8 +346,12 @@ def _build_chain(st: core.Stencil, T: int, pf: int, edge: Tuple[int, int],
     if n.stage is None:
       continue
     for pname, p in n.parents.items():
-      tlo, _ = n.tap_bounds(pname)
+      tlo, thi = n.tap_bounds(pname)
       p.window = max(p.window, n.delay - tlo[ax] - p.fill_delay + 1)
+      # the youngest plane of the parent any child reads (an input plane is
+      # first touched that many ticks after its load was issued)
+      first = n.delay - thi[ax] - p.fill_delay
+      p.first_use = first if p.first_use is None else min(p.first_use, first)
   return nodes, inputs, last_outputs
 
 
@@ -995,6 +1000,7 @@ class _MarchKernel:
         self.w('  {  // sliding sum of %s: the rows its window holds now' % n.var)
         self.w('    const int t = tau;')
         self._shifted = {}
+        self._wide = {}
         self._lx_read = set()
         self._stage_mark = len(self.L)
         self._emit_stage(n, 0, slide_init='only')
@@ -1028,6 +1034,7 @@ class _MarchKernel:
                   n.mirror_of.var, self.R, 2 * self.R - 1, j, self.V))
     # 2. compute every tensor's new plane
     self._shifted: Dict[Tuple[str, int, int, int, int], str] = {}
+    self._wide: Dict[str, str] = {}   # one-byte cells widened in this step
     self._lx_read = set()      # ('lds' shifts) lines already read in this step
     self._stage_mark = len(self.L)
     # (tensor, slot) whose end cells change hands at the end of this step: the
@@ -1100,6 +1107,7 @@ class _MarchKernel:
       if first > self.m_lo:                   # the loop starts at m_begin + m_lo
         guard = 't >= m_begin + (%d)' % first
         self._shifted = {}                     # temporaries live inside the guard
+        self._wide = {}
 
     early: List[str] = []
 
@@ -1116,8 +1124,23 @@ class _MarchKernel:
       c = e + off[0]
       lane_off, sub = c // self.V, c % self.V
       src = '%s[%d]' % (reg, sub)
+      # one-byte cells enter an expression as the int C promotes them to, with
+      # the value range hidden from the compiler (soda_rt.h soda_wide: hipcc's
+      # packed-byte instruction selection is wrong in places), once per cell
+      # and tick
+      byte = p.ctype in ('uint8_t', 'int8_t')
+
+      def wide(text: str, tag: str) -> str:
+        if not byte:
+          return text
+        if tag not in self._wide:
+          self._wide[tag] = 'w%d_%s' % (len(self._wide), tag)
+          _pre.append('      const int %s = soda_wide(%s);' %
+                      (self._wide[tag], text))
+        return self._wide[tag]
+
       if lane_off == 0:
-        return src
+        return wide(src, '%s_e%d' % (reg, sub))
       if self.cfg.lane_shift == 'none':
         return src       # TIMING EXPERIMENTS ONLY: wrong results
       if id(p) in self.ldsx and abs(lane_off) == 1 and age == 1:
@@ -1173,7 +1196,7 @@ class _MarchKernel:
             and not p.xs
         (_early if early else _pre).append(line)
         self._shifted[key] = tmp
-      return self._shifted[key]
+      return wide(self._shifted[key], self._shifted[key])
 
     body: List[str] = []
     dst_slot = self.slot_of(n, k, 0)
@@ -1324,6 +1347,7 @@ class _MarchKernel:
     if guard:
       self.w('      }')
       self._shifted = {}
+      self._wide = {}
     if n.to_lds:   # hand the new plane to the next wave of the block
       for j in self.rows_of(n):
         self.w('      soda_store_frag<%s, %d, false>(&soda_ring_%s[t & %d][%d]'

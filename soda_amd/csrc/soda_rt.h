@@ -103,6 +103,21 @@ SODA_DEV int soda_opaque(int v) {
   return v;
 }
 
+// A one-byte cell as the int C promotes it to, its value range HIDDEN from the
+// compiler (an empty asm).  hipcc (ROCm 7.2, every level above -O0) turns
+// expressions over bytes it knows to be bytes into packed-byte instructions --
+// v_dot4_u32_u8 over v_perm_b32-assembled operands, SDWA byte selects -- and
+// gets some of them wrong next to a min / max and lane-shifted copies (round
+// 4, tools/fuzz_scan.py deep seed 159 and its reduction: a quarter of the
+// cells of a uint8 program, exact at -O0; round 3, seed 613: v_min_i32_sdwa).
+// An operand that is "some int" takes the plain 32-bit instructions.
+template <class T>
+SODA_DEV int soda_wide(T v) {
+  int w = (int)v;
+  asm volatile("" : "+v"(w));
+  return w;
+}
+
 // every element of a fragment in a 32-bit register of its own (no instruction:
 // the value passes through an empty asm the compiler cannot see through)
 template <class T, int V>

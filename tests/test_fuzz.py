@@ -358,3 +358,47 @@ def test_one_byte_locals_in_fused_kernels(built, opts):
     lo, hi = stencil.valid_box(extent, o)
     idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
     assert np.array_equal(got[o][idx], want[o][idx]), o
+
+
+BYTES_NEXT_TO_A_MIN = """kernel: bytes159
+burst width: 64
+unroll factor: 2
+iterate: %d
+input uint8: in0(32, *)
+input uint8: in1
+local uint16: loc0(0, 0) = in1(2, 0) * 43 * (min(16, 32) * in0(1, 0)) - (in1(-1, -1) + 10) * in1(0, -2) + (in0(2, -2) - in0(2, 1)) * 40 + in0(1, 2)
+output uint8: out0(0, 0) = in1(2, 1) * 1
+output uint8: out1(0, 0) = (min(int32(in0(-2, 1)), 4) + in1(-2, -2) * in1(2, -1) - %sin0(1, -2) * in1(0, 1)) / 6
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('iterate,with_u3', [(1, True), (1, False), (5, True)])
+def test_one_byte_inputs_next_to_a_min_and_lane_shifts(built, iterate, with_u3):
+  """tools/fuzz_scan.py deep, seed 159 (round 4) and its reduction: products of
+  one-byte INPUT cells next to a min() and lane-shifted copies.  hipcc (every
+  level above -O0) selected packed-byte instructions for them -- v_dot4_u32_u8
+  over v_perm_b32-assembled operands, SDWA byte selects -- and a quarter of the
+  cells came out wrong (the dead local `loc0` only shapes the code enough to
+  trigger it).  The marching kernels now hand one-byte cells to expressions as
+  ints of hidden range (soda_rt.h soda_wide)."""
+  from soda_amd import runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  text = BYTES_NEXT_TO_A_MIN % (iterate,
+                                '(in0(2, -2) + 8 * 16) - ' if with_u3 else '')
+  stencil = core.from_text(text)
+  extent = (520, 291)
+  rng = np.random.default_rng(4401)
+  ins = {n: rng.integers(1, 201, extent[::-1]).astype(np.uint8)
+         for n in stencil.input_names}
+  want = c_oracle.COracle(stencil).run(ins)
+  for kw in (dict(), dict(peel=0, prefetch=1), dict(vec=4, chunk_rows=16)):
+    with runtime.Program(stencil, lower.LowerOptions(**kw),
+                         extent=extent) as prog:
+      got = prog.run(ins)
+      assert {p.kind for p in prog.module.passes} == {'march2d'}
+    for o in stencil.output_names:
+      lo, hi = stencil.valid_box(extent, o)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      assert np.array_equal(got[o][idx], want[o][idx]), (kw, o)
