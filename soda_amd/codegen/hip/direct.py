@@ -48,6 +48,13 @@ def _global_interior(st: core.Stencil, stage: core.Stage, coord) -> List[str]:
   return conds
 
 
+def _wide(table, name: str, text: str) -> str:
+  """A one-byte cell enters an expression as the int C promotes it to, its
+  value range hidden from the compiler (soda_rt.h soda_wide: hipcc's
+  packed-byte instruction selection is wrong in places)."""
+  return 'soda_wide(%s)' % text if table[name].size_in_bytes == 1 else text
+
+
 def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
                         vec: int) -> Tuple[List[str], Tuple[int, ...]]:
   """`direct` with `vec` cells per thread: every row of a parent the stage taps
@@ -151,7 +158,7 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
                     '%s[i] = soda_p[i]; }' % (n, var))
         rows[key] = (var, mn)
       var, mn = rows[key]
-      return '%s[%d]' % (var, off[0] - mn + e)
+      return _wide(table, ref.name, '%s[%d]' % (var, off[0] - mn + e))
     return load
 
   counter = [0]
@@ -178,7 +185,7 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
       if off:
         terms.append('(%d)' % off if d == 0 else
                      '(%d) * a.stride[%d]' % (off, d))
-    return 'in_%s[%s]' % (ref.name, ' + '.join(terms))
+    return _wide(table, ref.name, 'in_%s[%s]' % (ref.name, ' + '.join(terms)))
 
   L.append('    _Pragma("unroll") for (int e = 0; e < %d; ++e) {' % V)
   cell_ok = ['%s + e >= %d' % (_COORDS[0], lo[0]),
@@ -261,7 +268,7 @@ def add_direct_pass(mod: Module, vec: int = 1) -> PassDesc:
         if off:
           terms.append('(%d)' % off if d == 0 else
                        '(%d) * a.stride[%d]' % (off, d))
-      return 'in_%s[%s]' % (ref.name, ' + '.join(terms))
+      return _wide(table, ref.name, 'in_%s[%s]' % (ref.name, ' + '.join(terms)))
 
     for let in stage.stmt.let:
       lines.append('    const %s %s = %s;' %
