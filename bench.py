@@ -262,6 +262,36 @@ def group_main(args):
   for e in extent:
     cells *= e
   table = stencil.symbol_table
+  parity = None
+  if not args.no_parity:
+    # the same result check as the rank-per-GPU path: two chained steps from
+    # the seeded input (the second opens with the exchange), gathered by the
+    # library, against the CPU oracle (test infrastructure, the checker only)
+    from oracle import c_oracle
+    with runtime.Group(stencil, extent, devices, opts,
+                       exchange_every=args.exchange_every, overlap=way,
+                       calibrate=True) as group:
+      rng = np.random.default_rng(1234)
+      host_in = {name: rng.random(tuple(extent[::-1]), dtype=np.float32)
+                 for name in stencil.input_names}
+      group.load(host_in)
+      group.run()
+      group.run()
+      got = group.store(2 * args.iterate)
+    want = c_oracle.COracle(stencil, openmp=True).run(
+        host_in, iterate=2 * args.iterate)
+    checked = bad = 0
+    for o in stencil.output_names:
+      lo, hi = stencil.valid_box(extent, o, 2 * args.iterate)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      g = np.ascontiguousarray(got[o][idx]).view(np.uint32)
+      w = np.ascontiguousarray(want[o][idx]).view(np.uint32)
+      checked += int(g.size)
+      bad += int((g != w).sum())
+    parity = {'cells': checked, 'mismatches': bad,
+              'against': 'oracle/c_oracle.py (OpenMP), %d iterations from the '
+                         'seeded input, valid box, bit for bit' %
+                         (2 * args.iterate)}
   print(json.dumps({
       'metric': 'stencil cells*iters/s, %s %s iterate=%d' %
                 (stencil.app_name, 'x'.join(map(str, extent)), args.iterate),
@@ -288,7 +318,12 @@ def group_main(args):
           'copy_bytes_per_step': st['copy_bytes'],
           'host_enqueue_ms_per_step': enq / args.steps,
       },
+      **({'parity': parity} if parity else {}),
   }))
+  if parity and parity['mismatches']:
+    sys.stderr.write('bench.py: the checked steps differ from the oracle in '
+                     '%d cells\n' % parity['mismatches'])
+    sys.exit(3)
 
 
 class HostStagedP2P:

@@ -475,3 +475,26 @@ def test_split_passes_with_a_one_sided_reach(built):
       if l['wait'] and not l['record']:
         assert l['bnd_lo'] == 0          # nothing to wait for at the low end
   assert seen
+
+
+@pytest.mark.gpu
+def test_bench_group_mode_checks_its_result(built):
+  """`bench.py --group --virtual`: one process drives four slabs on the one
+  GPU through soda_hip_group_*, both exchange modes timed, and the JSON line
+  carries the result check -- two chained steps (the second opens with the
+  exchange) against the C oracle."""
+  import json
+  import subprocess
+  import sys
+  from conftest import ROOT
+  run = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--group', '--virtual',
+       '--gpus', '4', '--steps', '3', '--warmup', '1', '--extent', '2048',
+       '1600', '--iterate', '24', '--fuse', '12', '4', '--exchange-every',
+       '12'], capture_output=True, text=True, timeout=600)
+  assert run.returncode == 0, run.stderr[-3000:]
+  out = json.loads([l for l in run.stdout.splitlines()
+                    if l.startswith('{')][-1])
+  assert out['n_gpus'] == 4 and out['config']['exchanges_per_step'] == 2
+  assert out['parity']['mismatches'] == 0
+  assert out['parity']['cells'] == (2048 - 96) * (1600 - 96)
