@@ -6,7 +6,8 @@ bit; `group`: the same programs cut into virtual slabs (group_scan).
 `options`: random backend knobs on larger grids (options_scan).
 `wire`: behind the reference host's stream format (wire_scan).
 `deep`: 8-26 iterations at fusion depths up to 13 (deep_scan).
-Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire|deep FIRST LAST"""
+`ranks`: thread-ranks with the overlapped exchange under skew (ranks_scan).
+Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire|deep|ranks FIRST LAST"""
 import os
 import sys
 import time
@@ -325,6 +326,81 @@ def wire_scan(first, last):
   return 1 if failed else 0
 
 
+def ranks_scan(first, last):
+  """The rank-per-GPU path under random programs (round 4): iterable 2-D / 3-D
+  programs cut into 2-6 thread-ranks on the one GPU (tests/overlap_case.py:
+  dist.StreamOverlap + soda_hip_run_device_slab, messages by tests/fabric.py),
+  random exchange interval and fusion depth, two chained runs, one rank
+  spinning on the GPU and one sleeping on the host; against the C oracle."""
+  import fuzz
+  import overlap_case
+  from oracle import c_oracle
+  from soda_amd import core, util
+  ran = failed = skipped = 0
+  t0 = time.time()
+  for seed in range(first, last):
+    rng = np.random.default_rng(seed + 67000)
+    kind = ['plain', 'window', 'plain'][int(rng.integers(3))]
+    text, dim, _ = (fuzz.window_program(seed) if kind == 'window' else
+                    fuzz.program(seed))
+    if dim == 1:
+      continue
+    iterate = int(rng.integers(2, 9))
+    border = 'preserve' if rng.random() < 0.4 else None
+    try:
+      stencil = core.from_text(text, iterate=iterate,
+                               **({'border': border} if border else {}))
+      again = core.from_text(text, iterate=2 * iterate,
+                             **({'border': border} if border else {}))
+      if border:
+        stencil.check_preserve()
+    except util.SodaError:
+      continue
+    extent = ((int(rng.choice([64, 130, 258, 300])), int(rng.integers(150, 420)))
+              if dim == 2 else
+              (int(rng.choice([40, 64, 130])), int(rng.integers(10, 24)),
+               int(rng.integers(60, 130))))
+    lo, hi = again.valid_box(extent)
+    if not border and not all(h > l for l, h in zip(lo, hi)):
+      continue
+    world = int(rng.integers(2, 7))
+    every = int(rng.integers(1, iterate + 1))
+    fuse = [(), (2,), (3, 2), (4,)][int(rng.integers(4))]
+    spin = {int(rng.integers(world)): int(rng.integers(100_000, 1_500_000))} \
+        if rng.random() < 0.6 else {}
+    sleep = {int(rng.integers(world)): float(rng.uniform(0.0002, 0.002))} \
+        if rng.random() < 0.4 else {}
+    ins = fuzz.inputs_for(stencil, extent, seed)
+    want = c_oracle.COracle(again, openmp=False).run(ins)
+    what = ('seed %d %s dim %d iterate 2 x %d border %s extent %s world %d '
+            'every %d fuse %s spin %s sleep %s' %
+            (seed, kind, dim, iterate, border, extent, world, every, fuse,
+             spin, sleep))
+    try:
+      with overlap_case.Case(stencil, extent, every, fuse, world) as case:
+        got, _ = case.trial(ins, iterate, runs=2, spin=spin, sleep=sleep)
+    except util.SodaError as e:
+      if 'thinner' in str(e) or 'ghost' in str(e):
+        skipped += 1
+        continue
+      failed += 1
+      print('%s: %s: %s\n%s' % (what, type(e).__name__, str(e)[:300], text),
+            flush=True)
+      continue
+    ran += 1
+    bad = overlap_case.mismatches(again, extent, got, want, 2 * iterate,
+                                  whole_grid=bool(border), by_value=True)
+    if bad:
+      failed += 1
+      print('%s: %d cells differ\n%s' % (what, bad, text), flush=True)
+    if ran % 25 == 0:
+      print('... %d rank groups, %d failures, %d skipped, %.0f s' %
+            (ran, failed, skipped, time.time() - t0), flush=True)
+  print('ranks seeds [%d, %d): %d rank groups run, %d skipped (slabs thinner '
+        'than their ghosts), %d failures' % (first, last, ran, skipped, failed))
+  return 1 if failed else 0
+
+
 def deep_scan(first, last):
   """Deep temporal blocking on random programs (round 4: the scans above fuse
   at most 3 iterations, bench.py fuses 13): iterable 2-D programs of the plain
@@ -417,6 +493,8 @@ def deep_scan(first, last):
 
 
 if __name__ == '__main__':
+  if sys.argv[1] == 'ranks':
+    sys.exit(ranks_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'deep':
     sys.exit(deep_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'wire':
