@@ -7,7 +7,7 @@ bit; `group`: the same programs cut into virtual slabs (group_scan).
 `wire`: behind the reference host's stream format (wire_scan).
 `deep`: 8-26 iterations at fusion depths up to 13 (deep_scan).
 `ranks`: thread-ranks with the overlapped exchange under skew (ranks_scan).
-Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire|deep|ranks FIRST LAST"""
+Usage: python tools/fuzz_scan.py window|generic|rich|group|options|wire|deep|ranks|wide FIRST LAST"""
 import os
 import sys
 import time
@@ -401,6 +401,51 @@ def ranks_scan(first, last):
   return 1 if failed else 0
 
 
+def wide_scan(first, last):
+  """Random wide-window programs (tests/fuzz_nest.py `wide`) through
+  --hip-strategy ldswin -- 4 and 8 rows per step, random chunk lengths --
+  against their own C++ nests (nothing shared with the product)."""
+  import fuzz_nest
+  from soda_amd import core, runtime, util
+  from soda_amd.codegen.hip import lower
+  ran = failed = refused = 0
+  t0 = time.time()
+  for seed in range(first, last):
+    rng = np.random.default_rng(seed + 71000)
+    prog, extent = fuzz_nest.program(seed, 'wide')
+    if fuzz_nest.has_empty_box(prog, extent):
+      continue
+    extent = (int(rng.choice([36, 260, 520, 1028, 1540, 2052])),
+              int(rng.integers(40, 260)))
+    if fuzz_nest.has_empty_box(prog, extent):
+      continue
+    stencil = core.from_text(prog.soda_text())
+    ins = fuzz_nest.inputs_for(prog, extent, seed)
+    want = prog.run(ins, extent)
+    kw = dict(strategy='ldswin', waves_y=int(rng.choice([1, 4, 8])),
+              chunk_rows=int(rng.choice([8, 24, 40, 64, 100])))
+    try:
+      with runtime.Program(stencil, lower.LowerOptions(**kw),
+                           extent=extent) as hip:
+        got = hip.run(ins)
+    except util.SodaError:
+      refused += 1
+      continue
+    ran += 1
+    for o in stencil.output_names:
+      if not np.array_equal(got[o], want[o], equal_nan=True):
+        failed += 1
+        print('seed %d extent %s %s output %s: %d cells differ\n%s' %
+              (seed, extent, kw, o, int((got[o] != want[o]).sum()),
+               prog.soda_text()), flush=True)
+    if ran % 25 == 0:
+      print('... %d programs, %d failures, %d refused, %.0f s' %
+            (ran, failed, refused, time.time() - t0), flush=True)
+  print('wide seeds [%d, %d): %d programs run, %d refused, %d failures' %
+        (first, last, ran, refused, failed))
+  return 1 if failed else 0
+
+
 def deep_scan(first, last):
   """Deep temporal blocking on random programs (round 4: the scans above fuse
   at most 3 iterations, bench.py fuses 13): iterable 2-D programs of the plain
@@ -493,6 +538,8 @@ def deep_scan(first, last):
 
 
 if __name__ == '__main__':
+  if sys.argv[1] == 'wide':
+    sys.exit(wide_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'ranks':
     sys.exit(ranks_scan(int(sys.argv[2]), int(sys.argv[3])))
   if sys.argv[1] == 'deep':
