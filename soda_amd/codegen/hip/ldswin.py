@@ -69,6 +69,27 @@ def ldswin_supported(stencil: core.Stencil) -> Optional[str]:
   return None
 
 
+def ldswin_candidate(stencil: core.Stencil) -> bool:
+  """Cheap test on the program AS WRITTEN, before `lower` folds its pointwise
+  locals into one stage (which re-parses the program and duplicates a local
+  per read): everything `ldswin_pays` will ask of the folded form that can
+  already be read off the unfolded one."""
+  if stencil.dim != 2 or stencil.iterate != 1 or \
+      len(stencil.input_names) != 1 or len(stencil.output_names) != 1 or \
+      stencil.param_stmts or stencil.preserve_border:
+    return False
+  table = stencil.symbol_table
+  out = stencil.output_names[0]
+  if table[stencil.input_names[0]].size_in_bytes != 4 or \
+      table[out].size_in_bytes != 4:
+    return False
+  lo, hi = stencil.iteration_boxes()[out]
+  work = sum(ir.op_count(s.stmt.expr) + sum(ir.op_count(l.expr)
+                                            for l in s.stmt.let)
+             for s in stencil.ordered_stages)
+  return hi[0] - lo[0] >= MIN_SPAN and work >= MIN_OPS
+
+
 def ldswin_pays(stencil: core.Stencil) -> bool:
   """Whether `auto` should pick it: a wide window and enough arithmetic."""
   if ldswin_supported(stencil):

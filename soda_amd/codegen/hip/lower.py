@@ -45,7 +45,8 @@ from soda_amd.codegen.hip.direct import DIRECT_BLOCK, add_direct_pass  # noqa: F
 from soda_amd.codegen.hip.lds2d import (add_lds2d_pass,  # noqa: F401
                                         lds2d_supported)
 from soda_amd.codegen.hip.ldswin import (add_ldswin_pass,  # noqa: F401
-                                         ldswin_pays, ldswin_supported)
+                                         ldswin_candidate, ldswin_pays,
+                                         ldswin_supported)
 from soda_amd.codegen.hip.march import (MAX_FUSE_3D, MAX_FUSE_PRESERVE,  # noqa: F401
                                         MAX_SHIFT_TEMPS,
                                         MAX_UNROLL, REG_BUDGET, MarchConfig,
@@ -266,18 +267,29 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
   # -- is a sub-expression there.  On request, and by itself where it pays
   # (contrast: one input, 17 x 17 taps, 393 operations per cell)
   if opts.strategy in ('auto', 'ldswin') and stencil.dim == 2 and \
-      os.environ.get('SODA_HIP_LDSWIN', '1') != '0':
+      os.environ.get('SODA_HIP_LDSWIN', '1') != '0' and \
+      (opts.strategy == 'ldswin' or ldswin_candidate(stencil)):
     from soda_amd.optimization import pointwise
-    whole = pointwise.inline_pointwise(stencil, fold_groups=True,
-                                       max_ops=1 << 20)
+    # (`auto`: a finite cap on the folded expression -- a local read k times
+    # at one index is duplicated k times per level; contrast folds to ~400)
+    whole = pointwise.inline_pointwise(
+        stencil, fold_groups=True,
+        max_ops=1 << 20 if opts.strategy == 'ldswin' else 1 << 13)
     if same_boxes(whole) and (
         (opts.strategy == 'ldswin' and ldswin_supported(whole) is None) or
         (opts.strategy == 'auto' and ldswin_pays(whole) and
          (opts.vec is None or opts.vec % 4 == 0))):
       mod = Module(whole)
-      add_ldswin_pass(mod, chunk=opts.chunk_rows or 64,
-                      step=opts.waves_y if opts.waves_y > 1 else None)
-      return mod
+      try:
+        add_ldswin_pass(mod, chunk=opts.chunk_rows or 64,
+                        step=opts.waves_y if opts.waves_y > 1 else None)
+        return mod
+      except util.SemanticError:
+        # the ring does not fit LDS (window too tall / too wide): only an
+        # explicit `ldswin` request hears about it, `auto` moves on to the
+        # marching / direct ladder with the program as written
+        if opts.strategy == 'ldswin':
+          raise
   if opts.strategy == 'ldswin':
     raise util.SemanticError('ldswin: %s' % (
         ldswin_supported(stencil) or 'the program does not fold to one stage'))

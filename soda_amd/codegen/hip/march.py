@@ -1152,7 +1152,7 @@ class _MarchKernel:
           # line still holds the row wanted: read it here)
           self._lx_read.add((p.var, _k))
           _pre.extend(self._lx_reads(p))
-        return name
+        return wide(name, name)
       key = (p.var, slot, row, sub, lane_off)
       if key not in self._shifted:
         tmp = 'sh_%s_e%d_%s%d' % (reg, sub, 'm' if lane_off < 0 else 'p',

@@ -28,9 +28,12 @@ touch the GPU's memory through the CPU whenever they get to it, so a rehearsal
 over gloo must stage device tensors through host buffers itself
 (bench.py HostStagedP2P, tests/test_dist.py _gpu_worker).
 """
+import logging
 from typing import Callable, List, Optional, Sequence, Tuple
 
 from soda_amd import core, util
+
+_log = logging.getLogger(__name__)
 
 
 class Slab:
@@ -348,7 +351,10 @@ def planned_exchange_every(stencil: core.Stencil, extent: Sequence[int],
     if multiple_of > 1 and multiple_of <= k < iterate:
       k = k // multiple_of * multiple_of
     return min(k, iterate)
-  except Exception:          # noqa: BLE001 -- a planning aid must not stop a run
+  except Exception as e:     # noqa: BLE001 -- a planning aid must not stop a run
+    # ... but a broken planner must not degrade K silently for ever either
+    _log.warning('planned_exchange_every: planner failed (%s: %s); exchanging '
+                 'every %d iterations instead', type(e).__name__, e, fallback)
     return fallback
 
 

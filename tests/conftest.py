@@ -11,8 +11,19 @@ SODA_DIR = os.path.join(ROOT, 'tests', 'golden', 'soda')
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 
+def pytest_addoption(parser):
+  parser.addoption(
+      '--fuzz-budget', default=None,
+      help='scale the random-program GPU seed sets (tests/fuzz.py '
+      'budget_seeds): 1 = sized for the ~10-minute driver run (default), 2 = '
+      'the full sets of earlier rounds, 0.5 = half')
+
+
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by gpurun)')
+  # (test modules read it at import, i.e. during collection, after this hook)
+  if config.getoption('--fuzz-budget') is not None:
+    os.environ['SODA_FUZZ_BUDGET'] = str(config.getoption('--fuzz-budget'))
 
 
 # kernel names a GPU test of this session has compared with the oracle

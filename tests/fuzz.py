@@ -12,6 +12,24 @@ FLOAT_TYPES = ['float', 'double']
 INT_TYPES = ['uint8', 'int16', 'uint16', 'int32']
 
 
+def budget() -> float:
+  """`--fuzz-budget` / $SODA_FUZZ_BUDGET: how much of the GPU run's time the
+  random-program tests may take, relative to the default sets."""
+  import os
+  try:
+    return max(0.0, float(os.environ.get('SODA_FUZZ_BUDGET', '1') or 1))
+  except ValueError:
+    return 1.0
+
+
+def budget_seeds(default: int, full: int, pinned=()):
+  """Seeds 0 .. n-1 with n = `default` scaled by the budget (never more than
+  `full`, the set earlier rounds ran; never fewer than 4), plus `pinned`
+  (seeds that once found a defect stay in whatever the budget)."""
+  n = min(full, max(4, int(round(default * budget()))))
+  return list(range(n)) + [s for s in pinned if s >= n]
+
+
 def _idx(rng, dim, radius):
   return tuple(int(rng.integers(-radius, radius + 1)) for _ in range(dim))
 

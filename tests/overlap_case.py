@@ -60,7 +60,8 @@ class Case:
     from soda_amd import dist as sdist
     st = self.stencil
     spin, sleep = spin or {}, sleep or {}
-    counts = {'splits': 0, 'intervals': 0}
+    # per rank: `d[k] += 1` from 5-6 rank threads is not atomic under the GIL
+    counts = [{'splits': 0, 'intervals': 0} for _ in range(self.world)]
 
     def rank_fn(rank, endpoint):
       slab, prog = self.slabs[rank], self.progs[rank]
@@ -81,8 +82,8 @@ class Case:
                           [t.data_ptr() for t in cur], lext, iterate=iters,
                           stream=compute.cuda_stream, origin=slab.origin,
                           global_extent=slab.extent, **kw)
-          counts['splits'] += prog.last_split()
-          counts['intervals'] += 1
+          counts[rank]['splits'] += prog.last_split()
+          counts[rank]['intervals'] += 1
 
         res = sdist.run(slab, src, work[0], work[1], step, iterate, endpoint,
                         overlap=hider)
@@ -99,8 +100,8 @@ class Case:
       return own, endpoint.messages
 
     results = fabric.run_ranks(self.world, rank_fn)
-    self.splits += counts['splits']
-    self.intervals += counts['intervals']
+    self.splits += sum(c['splits'] for c in counts)
+    self.intervals += sum(c['intervals'] for c in counts)
     got = {o: np.concatenate([r[0][i] for r in results], axis=0)
            for i, o in enumerate(st.output_names)}
     return got, [r[1] for r in results]

@@ -572,7 +572,8 @@ def test_bench_launcher_on_the_gpu_box():
     assert not run.stdout.strip()
 
 
-def test_exchange_interval_by_the_librarys_cost_choice(built):
+def test_exchange_interval_by_the_librarys_cost_choice(built, caplog,
+                                                       monkeypatch):
   """dist.planned_exchange_every: the rank-per-GPU path asks the library
   (soda_hip_group_plan, a pure function) like the one-process group does; the
   headline run keeps its single interval, the long runs exchange a little less
@@ -599,3 +600,15 @@ def test_exchange_interval_by_the_librarys_cost_choice(built):
   # a description the library refuses falls back to the rule
   assert sdist.planned_exchange_every(st, (8192, 8), 8, 100) == \
       sdist.auto_exchange_every(st, (8192, 8), 8, 100)
+  # ... and so does a planner that breaks -- but it says so (a bare
+  # `except` used to degrade K silently for ever)
+  from soda_amd import runtime
+
+  def broken():
+    raise RuntimeError('no library today')
+  monkeypatch.setattr(runtime, 'library', broken)
+  caplog.set_level('WARNING', logger='soda_amd.dist')
+  assert sdist.planned_exchange_every(long, (8192, 8192), 8, 1000) == \
+      sdist.auto_exchange_every(long, (8192, 8192), 8, 1000)
+  assert any('planner failed' in r.getMessage() and 'no library today' in
+             r.getMessage() for r in caplog.records)

@@ -11,10 +11,14 @@ import fuzz
 from soda_amd import core, util
 
 CPU_SEEDS = range(0, 40)
-# (round 4: 50 of the former 100 -- the driver's GPU run has ~10 minutes, and
-# tests/test_fuzz_nest.py now runs 3 x 30 programs against nests that do not
-# share the product's front-end; tools/fuzz_scan.py ran thousands beyond these)
-GPU_SEEDS = range(0, 50)
+# The GPU seed sets scale with `--fuzz-budget B` (tests/conftest.py; env
+# SODA_FUZZ_BUDGET): B = 1, the default, is sized for the driver's GPU run
+# (~10 minutes for the whole suite; tests/test_fuzz_nest.py runs 3 x 30 more
+# programs against nests that do not share the product's front-end); B = 2
+# restores the full sets of rounds 2-3 (100 / 100 / 45 / 60 seeds) for a
+# nightly-style run; B < 1 shortens them.  Seeds that once found a defect are
+# pinned in every set, whatever the budget.
+GPU_SEEDS = fuzz.budget_seeds(50, 100)
 
 
 def _build(seed):
@@ -79,6 +83,31 @@ def test_every_gpu_seed_lowers_without_a_gpu():
   assert lowered > 400
 
 
+def _tall_window(w: int, h: int) -> str:
+  taps = ' + '.join('in0(%d, %d)' % (x, y) for y in range(h) for x in range(w))
+  return ('kernel: tall\nburst width: 64\nunroll factor: 2\niterate: 1\n'
+          'input float: in0(64, *)\noutput float: out0(0, 0) = %s\n' % taps)
+
+
+@pytest.mark.parametrize('w,h', [(3, 41), (6, 41), (300, 1)])
+def test_auto_survives_windows_the_lds_ring_cannot_hold(w, h):
+  """`ldswin_pays` asks for a wide window and enough arithmetic,
+  `add_ldswin_pass` then refuses rings that do not fit LDS (too tall / too
+  wide).  `auto` must move on to the marching / direct ladder; only an
+  explicit `--hip-strategy ldswin` hears the refusal."""
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_text(_tall_window(w, h))
+  try:
+    mod = lower.lower(stencil, lower.LowerOptions(strategy='auto'))
+  except util.SemanticError as e:      # any OTHER family's refusal is fine
+    assert 'ldswin' not in str(e), e
+  else:
+    assert mod.kernels and mod.passes
+  if w >= 6:
+    with pytest.raises(util.SemanticError, match='ldswin'):
+      lower.lower(stencil, lower.LowerOptions(strategy='ldswin'))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('seed', GPU_SEEDS)
 def test_gpu_matches_oracle(built, seed):
@@ -127,7 +156,7 @@ def test_oracles_agree_with_preserved_border(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('seed', range(0, 45))
+@pytest.mark.parametrize('seed', fuzz.budget_seeds(45, 100))
 def test_gpu_matches_oracle_with_preserved_border(built, seed):
   from soda_amd import runtime
   from soda_amd.codegen.hip import lower
@@ -196,7 +225,7 @@ WINDOW_CPU_SEEDS = range(0, 24)
 # (109, 177, 283, 326, 454: found by tools/fuzz_scan.py -- min / max windows
 # along dimension 0 with fewer taps than the lane holds cells, uint8 at 16 cells
 # per lane, where no cell is common to all of a lane's windows)
-WINDOW_GPU_SEEDS = list(range(0, 28)) + [109, 177, 283, 326, 454]
+WINDOW_GPU_SEEDS = fuzz.budget_seeds(28, 45, pinned=(109, 177, 283, 326, 454))
 
 
 def _build_window(seed):
@@ -272,7 +301,7 @@ def test_gpu_matches_oracle_on_window_programs(built, seed):
 
 # -- the wider operator set (tests/fuzz.py _expr_rich) ------------------------
 RICH_CPU_SEEDS = range(0, 40)
-RICH_GPU_SEEDS = range(0, 38)
+RICH_GPU_SEEDS = fuzz.budget_seeds(38, 60)
 
 
 def _build_rich(seed):
