@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 6
+#define SODA_HIP_ABI_VERSION 7
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
 #define SODA_HIP_MAX_KERNELS 32
@@ -180,6 +180,15 @@ typedef struct soda_hip_plan {
                                           passes of least total cost that adds
                                           up to N, deepest first */
   soda_hip_pass_desc_t passes[SODA_HIP_MAX_PASSES];
+  /* ABI 7: cells ONE iteration of the program reads below / above a cell
+   * along the last dimension (the per-iteration growth of the outputs'
+   * windows, reference core.py:858-919), valid if has_reach != 0.  Lets the
+   * host-array entries cut a run into bands along that dimension -- each band
+   * a window run with iterate x reach ghost rows -- so that the copy-in of
+   * band i + 1 and the copy-out of band i - 1 run beside the kernels of band
+   * i; without it they copy in, run, copy out. */
+  int32_t has_reach;
+  int32_t reach_lo, reach_hi;
 } soda_hip_plan_t;
 
 typedef struct soda_hip_program soda_hip_program_t;   /* opaque */
@@ -367,6 +376,21 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           const soda_hip_host_tensor_t* outputs,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi);
+/* How the two entries above move data (soda_host.cpp): through pinned staging
+ * slots the program owns, ~16 MiB chunks along the last dimension
+ * (SODA_HIP_HOST_CHUNK_MB), packed / unpacked by a process-wide pool of worker
+ * threads (SODA_HIP_HOST_THREADS, default 8 -- the reference's pack and unpack
+ * loops carry `#pragma omp parallel for`, frt/host.py:193,357) while the DMA
+ * engine moves the neighbouring chunk.  The pack / unpack step alone, exported
+ * for callers that stage their own transfers and for tests without a GPU:
+ * copies box [lo, hi) between a strided host array (strides in elements) and
+ * a dense array that starts at index `row0` of the last dimension (0: holds
+ * the whole array); to_dense != 0: strided -> dense.  threads: 1 = the calling
+ * thread only, 0 = the pool. */
+int soda_hip_host_copy_box(void* strided, const int32_t* stride, void* dense,
+                           const int32_t* extent, const int32_t* lo,
+                           const int32_t* hi, int32_t dim, int32_t elem,
+                           int32_t to_dense, int32_t row0, int32_t threads);
 
 /* Measures one launch of every pass on `extent` (stand-in arrays; two warming
  * rounds, then four rounds of `launches` back-to-back launches per pass inside

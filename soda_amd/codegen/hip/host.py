@@ -72,6 +72,8 @@ def emit_plan(w, func: str, plan) -> None:
     w('  plan.passes[%d].cost = %rf;' % (i, float(p.cost)))
     for j in range(p.num_kernels):
       w('  plan.passes[%d].kernel[%d] = %d;' % (i, j, p.kernel[j]))
+  for field in ('has_reach', 'reach_lo', 'reach_hi'):
+    w('  plan.%s = %d;' % (field, getattr(plan, field)))
   w('  return plan;')
   w('}')
 

@@ -246,6 +246,8 @@ static int check_plan(const soda_hip_plan_t* p) {
   }
   if (p->passes[p->num_passes - 1].fused_iters != 1)
     return fail(SODA_HIP_ERR_INVALID, "plan: last pass must advance 1 iteration");
+  if (p->has_reach && (p->reach_lo < 0 || p->reach_hi < 0))
+    return fail(SODA_HIP_ERR_INVALID, "plan: negative reach");
   return SODA_HIP_OK;
 }
 
@@ -306,6 +308,13 @@ int soda_hip_program_destroy(soda_hip_program_t* p) {
     if (p->ev_bnd[i]) (void)hipEventDestroy(p->ev_bnd[i]);
   }
   if (p->side) (void)hipStreamDestroy(p->side);
+  for (auto& st : p->hstream)
+    if (st) (void)hipStreamDestroy(st);
+  p->ring_in.release();
+  p->ring_out.release();
+  for (auto& b : p->band_out)
+    if (b.ptr) (void)hipFree(b.ptr);
+  for (auto& e : p->hevents) (void)hipEventDestroy(e);
   if (p->module) (void)hipModuleUnload(p->module);
   delete p;
   return SODA_HIP_OK;
@@ -1346,161 +1355,6 @@ int soda_hip_last_rows(soda_hip_program_t* p, int64_t* rows) {
   if (!p || !rows) return fail(SODA_HIP_ERR_INVALID, "NULL argument");
   *rows = p->last_rows;
   return SODA_HIP_OK;
-}
-
-// -- host-array entry (soda::app::<app> analogue) ----------------------------
-
-}  // extern "C"
-
-namespace soda_detail {
-
-bool is_dense(const soda_hip_host_tensor_t& t, int dim) {
-  int64_t s = 1;
-  for (int d = 0; d < dim; ++d) {
-    if (t.stride[d] != s) return false;
-    s *= t.extent[d];
-  }
-  return true;
-}
-
-// copies box [lo, hi) between a strided host array and a dense staging array
-void copy_box(char* strided, const int32_t* stride, char* dense,
-              const int32_t* extent, const int32_t* lo, const int32_t* hi,
-              int dim, int elem, bool to_dense) {
-  int32_t idx[SODA_HIP_MAX_DIM];
-  int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
-  int64_t dstride[SODA_HIP_MAX_DIM], s = 1;
-  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
-    l[d] = d < dim ? lo[d] : 0;
-    h[d] = d < dim ? hi[d] : 1;
-    dstride[d] = s;
-    s *= d < dim ? extent[d] : 1;
-    if (h[d] <= l[d]) return;
-  }
-  for (idx[3] = l[3]; idx[3] < h[3]; ++idx[3])
-    for (idx[2] = l[2]; idx[2] < h[2]; ++idx[2])
-      for (idx[1] = l[1]; idx[1] < h[1]; ++idx[1]) {
-        int64_t so = 0, dof = 0;
-        for (int d = 1; d < SODA_HIP_MAX_DIM; ++d) {
-          so += d < dim ? (int64_t)idx[d] * stride[d] : 0;
-          dof += idx[d] * dstride[d];
-        }
-        if (stride[0] == 1) {
-          char* a = strided + (so + l[0]) * elem;
-          char* b = dense + (dof + l[0]) * elem;
-          if (to_dense) memcpy(b, a, (size_t)(h[0] - l[0]) * elem);
-          else memcpy(a, b, (size_t)(h[0] - l[0]) * elem);
-        } else {
-          for (int32_t x = l[0]; x < h[0]; ++x) {
-            char* a = strided + (so + (int64_t)x * stride[0]) * elem;
-            char* b = dense + (dof + x) * elem;
-            if (to_dense) memcpy(b, a, elem);
-            else memcpy(a, b, elem);
-          }
-        }
-      }
-}
-
-}  // namespace soda_detail
-
-extern "C" {
-
-int soda_hip_run_host_box(soda_hip_program_t* p,
-                          const soda_hip_host_tensor_t* inputs,
-                          const soda_hip_host_tensor_t* outputs,
-                          int32_t iterate, const int32_t* valid_lo,
-                          const int32_t* valid_hi) {
-  if (!p || !inputs || !outputs)
-    return fail(SODA_HIP_ERR_INVALID, "run_host: NULL argument");
-  const soda_hip_plan_t& plan = p->plan;
-  const int dim = plan.dim;
-  const int32_t* extent = inputs[0].extent;
-  if (!extent) return fail(SODA_HIP_ERR_INVALID, "run_host: NULL extent");
-  int64_t cells = 1;
-  for (int d = 0; d < dim; ++d) {
-    if (extent[d] < 1) return fail(SODA_HIP_ERR_INVALID, "run_host: extent < 1");
-    cells *= extent[d];
-  }
-  auto same_extent = [&](const soda_hip_host_tensor_t& t) {
-    if (!t.ptr || !t.extent || !t.stride) return false;
-    for (int d = 0; d < dim; ++d)
-      if (t.extent[d] != extent[d]) return false;
-    return true;
-  };
-  for (int i = 0; i < plan.num_inputs; ++i)
-    if (!same_extent(inputs[i]))
-      return fail(SODA_HIP_ERR_INVALID, "run_host: bad input tensor");
-  for (int o = 0; o < plan.num_outputs; ++o)
-    if (!same_extent(outputs[o]))
-      return fail(SODA_HIP_ERR_INVALID, "run_host: bad output tensor");
-  HIP_TRY(hipSetDevice(p->device));
-
-  int32_t zero[SODA_HIP_MAX_DIM] = {0, 0, 0, 0};
-  std::vector<char> staging;
-  std::vector<const void*> in_ptrs(plan.num_inputs);
-  std::vector<void*> out_ptrs(plan.num_outputs);
-  for (int i = 0; i < plan.num_inputs; ++i) {
-    size_t bytes = (size_t)cells * plan.elem_size[i];
-    int rc = ensure(p->host_in[i], bytes);
-    if (rc) return rc;
-    const void* host = inputs[i].ptr;
-    if (!is_dense(inputs[i], dim)) {
-      staging.resize(bytes);
-      copy_box(static_cast<char*>(inputs[i].ptr), inputs[i].stride,
-               staging.data(), extent, zero, extent, dim, plan.elem_size[i],
-               true);
-      host = staging.data();
-    }
-    HIP_TRY(hipMemcpy(p->host_in[i].ptr, host, bytes, hipMemcpyHostToDevice));
-    in_ptrs[i] = p->host_in[i].ptr;
-  }
-  for (int o = 0; o < plan.num_outputs; ++o) {
-    size_t bytes = (size_t)cells * plan.elem_size[plan.num_inputs + o];
-    int rc = ensure(p->host_out[o], bytes);
-    if (rc) return rc;
-    out_ptrs[o] = p->host_out[o].ptr;
-  }
-  const int prm0 = plan.num_inputs + plan.num_outputs + plan.num_locals;
-  for (int k = 0; k < plan.num_params; ++k) {
-    const soda_hip_host_tensor_t& t = inputs[plan.num_inputs + k];
-    if (!t.ptr) return fail(SODA_HIP_ERR_INVALID, "run_host: NULL param");
-    size_t bytes = (size_t)plan.param_elems[k] * plan.elem_size[prm0 + k];
-    int rc = ensure(p->host_prm[k], bytes);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(p->host_prm[k].ptr, t.ptr, bytes, hipMemcpyHostToDevice));
-    in_ptrs.push_back(p->host_prm[k].ptr);
-  }
-  int rc = soda_hip_run_device(p, out_ptrs.data(), in_ptrs.data(), extent,
-                               iterate, nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  for (int o = 0; o < plan.num_outputs; ++o) {
-    int elem = plan.elem_size[plan.num_inputs + o];
-    size_t bytes = (size_t)cells * elem;
-    const int32_t* lo = valid_lo ? valid_lo + o * dim : zero;
-    const int32_t* hi = valid_hi ? valid_hi + o * dim : extent;
-    bool whole = true;
-    for (int d = 0; d < dim; ++d)
-      whole = whole && lo[d] == 0 && hi[d] == extent[d];
-    if (whole && is_dense(outputs[o], dim)) {
-      HIP_TRY(hipMemcpy(outputs[o].ptr, out_ptrs[o], bytes,
-                        hipMemcpyDeviceToHost));
-    } else {
-      // only the valid box reaches the caller's array (frt/host.py:357-375)
-      staging.resize(bytes);
-      HIP_TRY(hipMemcpy(staging.data(), out_ptrs[o], bytes,
-                        hipMemcpyDeviceToHost));
-      copy_box(static_cast<char*>(outputs[o].ptr), outputs[o].stride,
-               staging.data(), extent, lo, hi, dim, elem, false);
-    }
-  }
-  return SODA_HIP_OK;
-}
-
-int soda_hip_run_host(soda_hip_program_t* p,
-                      const soda_hip_host_tensor_t* inputs,
-                      const soda_hip_host_tensor_t* outputs, int32_t iterate) {
-  return soda_hip_run_host_box(p, inputs, outputs, iterate, nullptr, nullptr);
 }
 
 // -- wire format: <app>_kernel on banked streams -------------------------------

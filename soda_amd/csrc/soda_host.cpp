@@ -1,0 +1,707 @@
+// soda_host.cpp -- the operator-level entry on HOST arrays,
+// soda_hip_run_host_box: what `soda::app::<app>()` is in the reference's
+// generated host (reference src/soda/codegen/frt/host.py:62-88; scatter
+// :181-249, WriteToDevice / Exec / ReadFromDevice / Finish :319-322, gather of
+// the valid box only :340-427).
+//
+// Rounds 1-4 copied with synchronous hipMemcpy from and to the caller's
+// pageable arrays and gathered the valid box through a std::vector: 82 ms for
+// the headline step (2 x 256 MiB moved, 1.1 ms of kernels).  Measured on the
+// pool's MI355X boxes (tools/experiments/r05_hostcopy_bench*.cpp,
+// profiles/r05_hostcopy*.jsonl): DMA from pinned memory 57 GB/s each way (48
+// each with both directions busy); hipHostRegister on a caller's fresh 4 KiB
+// pages 42 us/MiB and serialised between threads -- no faster than the
+// driver's own pageable path (11 ms per 256 MiB); host memcpy between pageable
+// and pinned memory 31 GB/s on one thread, 100 GB/s on eight.  So the copies
+// go through a ring of pinned staging slots the program owns: worker threads
+// pack chunk i+1 (the reference packs with `#pragma omp parallel for`,
+// frt/host.py:193) while the DMA engine moves chunk i, and the other way round
+// on the way out -- where only the valid box is written, straight from the
+// slot into the caller's (possibly strided) array.
+#include "soda_internal.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include <unistd.h>
+
+namespace soda_detail {
+
+// ---- worker threads -----------------------------------------------------------
+// One process-wide pool, made on first use, never destroyed (its threads sleep
+// on a condition variable between jobs and die with the process).  One job at
+// a time: callers from several threads take turns.  A forked child finds the
+// parent's pid and starts its own.
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static std::mutex make;
+    static CopyPool* pool = nullptr;
+    std::lock_guard<std::mutex> hold(make);
+    if (!pool || pool->pid_ != getpid()) pool = new CopyPool;   // (leaked)
+    return *pool;
+  }
+
+  int threads() const { return (int)workers_ + 1; }
+
+  // job(i) for every i in [0, count), on the workers and the caller
+  void run(size_t count, const std::function<void(size_t)>& job) {
+    if (count == 0) return;
+    if (count == 1 || workers_ == 0) {
+      for (size_t i = 0; i < count; ++i) job(i);
+      return;
+    }
+    std::lock_guard<std::mutex> turn(turn_);
+    {
+      std::lock_guard<std::mutex> hold(m_);
+      job_ = &job;
+      count_ = count;
+      next_.store(0, std::memory_order_relaxed);
+      active_ = workers_;
+      ++generation_;
+    }
+    wake_.notify_all();
+    work();
+    std::unique_lock<std::mutex> hold(m_);
+    done_.wait(hold, [this] { return active_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  CopyPool() : pid_(getpid()) {
+    long want = 8;
+    if (const char* v = getenv("SODA_HIP_HOST_THREADS")) want = atol(v);
+    const long have = (long)std::thread::hardware_concurrency();
+    if (have > 0 && want > have) want = have;
+    if (want < 1) want = 1;
+    workers_ = (size_t)want - 1;
+    for (size_t i = 0; i < workers_; ++i)
+      std::thread([this] { loop(); }).detach();
+  }
+
+  void work() {
+    for (;;) {
+      const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= count_) return;
+      (*job_)(i);
+    }
+  }
+
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> hold(m_);
+        wake_.wait(hold, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      work();
+      std::lock_guard<std::mutex> hold(m_);
+      if (--active_ == 0) done_.notify_one();
+    }
+  }
+
+  const pid_t pid_;
+  size_t workers_ = 0;
+  std::mutex turn_, m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(size_t)>* job_ = nullptr;
+  size_t count_ = 0, active_ = 0;
+  uint64_t generation_ = 0;
+  std::atomic<size_t> next_{0};
+};
+
+bool is_dense(const soda_hip_host_tensor_t& t, int dim) {
+  int64_t s = 1;
+  for (int d = 0; d < dim; ++d) {
+    if (t.stride[d] != s) return false;
+    s *= t.extent[d];
+  }
+  return true;
+}
+
+// Copies box [lo, hi) between a strided host array and a dense staging array
+// that holds the cells from index `row0` of the LAST dimension on (row0 = 0:
+// the whole array), with up to `threads` threads (0: the pool's).  A "line" is
+// a run along dimension 0; long lines are cut into segments so that a 1-D
+// array or a box of a few long rows still spreads over the threads.
+void copy_rows(char* strided, const int32_t* stride, char* dense,
+               const int32_t* extent, const int32_t* lo, const int32_t* hi,
+               int dim, int elem, bool to_dense, int32_t row0, int threads) {
+  int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
+  int64_t dstride[SODA_HIP_MAX_DIM], sstride[SODA_HIP_MAX_DIM], s = 1;
+  int64_t lines = 1;
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+    l[d] = d < dim ? lo[d] : 0;
+    h[d] = d < dim ? hi[d] : 1;
+    dstride[d] = s;
+    sstride[d] = d < dim ? stride[d] : 0;
+    s *= d < dim ? extent[d] : 1;
+    if (h[d] <= l[d]) return;
+    if (d > 0) lines *= h[d] - l[d];
+  }
+  const int64_t dense_shift = dim > 0 ? (int64_t)row0 * dstride[dim - 1] : 0;
+  const int64_t line_bytes = (int64_t)(h[0] - l[0]) * elem;
+  const bool unit = sstride[0] == 1;
+  const int64_t kSeg = 256 << 10;
+  const int64_t segs = unit ? (line_bytes + kSeg - 1) / kSeg : 1;
+  const int64_t pieces = lines * segs;
+  // ~1 MiB of copying per task, at least one piece
+  const int64_t piece_bytes = unit && line_bytes > kSeg ? kSeg : line_bytes;
+  int64_t per_task = ((unit ? 1 << 20 : 1 << 18) + piece_bytes - 1) /
+                     (piece_bytes > 0 ? piece_bytes : 1);
+  if (per_task < 1) per_task = 1;
+  const int64_t tasks = (pieces + per_task - 1) / per_task;
+  const int32_t n1 = h[1] - l[1], n2 = h[2] - l[2];
+  auto body = [&](size_t task) {
+    const int64_t first = (int64_t)task * per_task;
+    const int64_t last = first + per_task < pieces ? first + per_task : pieces;
+    for (int64_t p = first; p < last; ++p) {
+      const int64_t line = p / segs, seg = p % segs;
+      const int32_t i1 = l[1] + (int32_t)(line % n1);
+      const int32_t i2 = l[2] + (int32_t)((line / n1) % n2);
+      const int32_t i3 = l[3] + (int32_t)(line / ((int64_t)n1 * n2));
+      const int64_t so = i1 * sstride[1] + i2 * sstride[2] + i3 * sstride[3];
+      const int64_t dof = i1 * dstride[1] + i2 * dstride[2] + i3 * dstride[3] -
+                          dense_shift;
+      if (unit) {
+        const int64_t b0 = seg * kSeg;
+        const int64_t b1 = b0 + kSeg < line_bytes ? b0 + kSeg : line_bytes;
+        char* a = strided + (so + l[0]) * elem + b0;
+        char* b = dense + (dof + l[0]) * elem + b0;
+        if (to_dense) memcpy(b, a, (size_t)(b1 - b0));
+        else memcpy(a, b, (size_t)(b1 - b0));
+      } else {
+        for (int32_t x = l[0]; x < h[0]; ++x) {
+          char* a = strided + (so + (int64_t)x * sstride[0]) * elem;
+          char* b = dense + (dof + x) * elem;
+          if (to_dense) memcpy(b, a, elem);
+          else memcpy(a, b, elem);
+        }
+      }
+    }
+  };
+  const int64_t bytes = lines * line_bytes;
+  if (threads == 1 || tasks <= 1 || bytes < (2 << 20)) {
+    for (int64_t t = 0; t < tasks; ++t) body((size_t)t);
+    return;
+  }
+  CopyPool::get().run((size_t)tasks, body);
+}
+
+void copy_box(char* strided, const int32_t* stride, char* dense,
+              const int32_t* extent, const int32_t* lo, const int32_t* hi,
+              int dim, int elem, bool to_dense) {
+  copy_rows(strided, stride, dense, extent, lo, hi, dim, elem, to_dense, 0, 0);
+}
+
+// ---- the ring of pinned staging slots -------------------------------------------
+int HostRing::ensure(size_t want_slot_bytes, int want_slots) {
+  if (base && slot_bytes >= want_slot_bytes && slots >= want_slots)
+    return SODA_HIP_OK;
+  release();
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&base),
+                        want_slot_bytes * want_slots, hipHostMallocDefault));
+  slot_bytes = want_slot_bytes;
+  slots = want_slots;
+  for (int i = 0; i < slots; ++i)
+    HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+  return SODA_HIP_OK;
+}
+
+void HostRing::release() {
+  for (int i = 0; i < kMaxSlots; ++i)
+    if (ev[i]) {
+      (void)hipEventDestroy(ev[i]);
+      ev[i] = nullptr;
+    }
+  if (base) (void)hipHostFree(base);
+  base = nullptr;
+  slot_bytes = 0;
+  slots = 0;
+}
+
+namespace {
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(
+             std::chrono::steady_clock::now().time_since_epoch())
+      .count();
+}
+
+size_t chunk_target_bytes() {
+  // 16-32 MiB chunks sustain the DMA rate, 4 MiB halve it
+  // (profiles/r05_hostcopy.jsonl).  _KB: tests that want many chunks of a
+  // small array
+  if (const char* v = getenv("SODA_HIP_HOST_CHUNK_KB"))
+    if (atol(v) > 0) return (size_t)atol(v) << 10;
+  long mb = 16;
+  if (const char* v = getenv("SODA_HIP_HOST_CHUNK_MB")) mb = atol(v);
+  if (mb < 1) mb = 1;
+  return (size_t)mb << 20;
+}
+
+int make_events(std::vector<hipEvent_t>* pool, size_t count) {
+  while (pool->size() < count) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    pool->push_back(e);
+  }
+  return SODA_HIP_OK;
+}
+
+// What both ways of running share: the validated call, sizes, the rings.
+struct HostCall {
+  soda_hip_program* p;
+  const soda_hip_host_tensor_t* inputs;
+  const soda_hip_host_tensor_t* outputs;
+  int32_t iterate;
+  const int32_t* valid_lo;
+  const int32_t* valid_hi;
+  int dim, ax;
+  const int32_t* extent;
+  int32_t rows;            // extent of the last dimension
+  int64_t cells, plane;    // plane: cells per index of the last dimension
+  int64_t chunk_rows;      // rows per staged chunk
+  int slots;
+  int32_t zero[SODA_HIP_MAX_DIM] = {0, 0, 0, 0};
+  std::vector<const void*> in_ptrs;     // device: inputs, then params
+  bool in_used[HostRing::kMaxSlots] = {false, false, false, false};
+  int in_turn = 0;
+
+  const int32_t* lo(int o) const { return valid_lo ? valid_lo + o * dim : zero; }
+  const int32_t* hi(int o) const { return valid_hi ? valid_hi + o * dim : extent; }
+
+  // is the slot the next send() packs into free (its last DMA done)?
+  bool can_send() {
+    const int sl = in_turn % slots;
+    if (!in_used[sl]) return true;
+    if (hipEventQuery(p->ring_in.ev[sl]) == hipSuccess) return true;
+    (void)hipGetLastError();       // (hipErrorNotReady is not an error)
+    return false;
+  }
+
+  // rows [a, b) of input i: packed into a pinned slot, sent on `stream`
+  int send(int i, int64_t a, int64_t b, hipStream_t stream) {
+    const int elem = p->plan.elem_size[i];
+    const int sl = in_turn++ % slots;
+    if (in_used[sl]) HIP_TRY(hipEventSynchronize(p->ring_in.ev[sl]));
+    char* slot = p->ring_in.base + (size_t)sl * p->ring_in.slot_bytes;
+    int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
+    for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+      l[d] = 0;
+      h[d] = d < dim ? extent[d] : 1;
+    }
+    l[ax] = (int32_t)a;
+    h[ax] = (int32_t)b;
+    copy_rows(static_cast<char*>(inputs[i].ptr), inputs[i].stride, slot, extent,
+              l, h, dim, elem, true, (int32_t)a, 0);
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(p->host_in[i].ptr) +
+                               (size_t)a * plane * elem,
+                           slot, (size_t)(b - a) * plane * elem,
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(p->ring_in.ev[sl], stream));
+    in_used[sl] = true;
+    return SODA_HIP_OK;
+  }
+
+  // rows [a, b) of output o, `dev` = where row `dev_row0` of it lives on the
+  // device: fetched into slot `sl` on `stream`
+  int fetch(int o, int64_t a, int64_t b, const void* dev, int64_t dev_row0,
+            int sl, hipStream_t stream) {
+    const int elem = p->plan.elem_size[p->plan.num_inputs + o];
+    char* slot = p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes;
+    HIP_TRY(hipMemcpyAsync(slot,
+                           static_cast<const char*>(dev) +
+                               (size_t)(a - dev_row0) * plane * elem,
+                           (size_t)(b - a) * plane * elem,
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(p->ring_out.ev[sl], stream));
+    return SODA_HIP_OK;
+  }
+
+  // the valid box's part of rows [a, b) of output o: slot -> caller's array
+  // (frt/host.py:357-375: nothing outside the box is touched)
+  void deliver(int o, int64_t a, int64_t b, int sl) {
+    const int elem = p->plan.elem_size[p->plan.num_inputs + o];
+    char* slot = p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes;
+    int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
+    for (int k = 0; k < SODA_HIP_MAX_DIM; ++k) {
+      l[k] = k < dim ? lo(o)[k] : 0;
+      h[k] = k < dim ? hi(o)[k] : 1;
+    }
+    l[ax] = (int32_t)a;
+    h[ax] = (int32_t)b;
+    copy_rows(static_cast<char*>(outputs[o].ptr), outputs[o].stride, slot,
+              extent, l, h, dim, elem, false, (int32_t)a, 0);
+  }
+
+  bool empty(int o) const {
+    for (int d = 0; d < dim; ++d)
+      if (hi(o)[d] <= lo(o)[d]) return true;
+    return false;
+  }
+};
+
+// Copy in, run, copy out, on one stream; packing overlaps the DMA of the
+// previous chunk, the DMA runs `slots` chunks ahead of the unpacking.
+int run_whole(HostCall& c) {
+  soda_hip_program* p = c.p;
+  const soda_hip_plan_t& plan = p->plan;
+  hipStream_t stream = p->hstream[0];
+  for (int i = 0; i < plan.num_inputs; ++i)
+    for (int64_t a = 0; a < c.rows; a += c.chunk_rows) {
+      const int64_t b = a + c.chunk_rows < c.rows ? a + c.chunk_rows : c.rows;
+      if (int rc = c.send(i, a, b, stream)) return rc;
+    }
+  std::vector<void*> out_ptrs(plan.num_outputs);
+  for (int o = 0; o < plan.num_outputs; ++o) {
+    size_t bytes = (size_t)c.cells * plan.elem_size[plan.num_inputs + o];
+    if (int rc = ensure(p->host_out[o], bytes)) return rc;
+    out_ptrs[o] = p->host_out[o].ptr;
+  }
+  if (int rc = soda_hip_run_device(p, out_ptrs.data(), c.in_ptrs.data(),
+                                   c.extent, c.iterate, stream))
+    return rc;
+  for (int o = 0; o < plan.num_outputs; ++o) {
+    if (c.empty(o)) continue;
+    const int64_t r0 = c.lo(o)[c.ax], r1 = c.hi(o)[c.ax];
+    const int64_t nchunk = (r1 - r0 + c.chunk_rows - 1) / c.chunk_rows;
+    for (int64_t k = 0; k < nchunk + c.slots - 1; ++k) {
+      if (k < nchunk) {
+        const int64_t a = r0 + k * c.chunk_rows;
+        const int64_t b = a + c.chunk_rows < r1 ? a + c.chunk_rows : r1;
+        if (int rc = c.fetch(o, a, b, out_ptrs[o], 0, (int)(k % c.slots), stream))
+          return rc;
+      }
+      const int64_t d = k - (c.slots - 1);       // the chunk to unpack now
+      if (d >= 0) {
+        const int64_t a = r0 + d * c.chunk_rows;
+        const int64_t b = a + c.chunk_rows < r1 ? a + c.chunk_rows : r1;
+        HIP_TRY(hipEventSynchronize(p->ring_out.ev[d % c.slots]));
+        c.deliver(o, a, b, (int)(d % c.slots));
+      }
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(stream));   // (the param copies, an empty box)
+  return SODA_HIP_OK;
+}
+
+// Bands along the last dimension, each a window run with iterate x reach ghost
+// rows (the slab mechanism of a multi-GPU run, soda_hip_run_device_slab, with
+// the PCIe link in the place of xGMI): three streams -- copies in, kernels,
+// copies out -- so that the link is busy in both directions while band i
+// computes.  One host thread drives all of it; whatever it finds to do next,
+// in this order: deliver a fetched chunk, fetch one, launch a band whose
+// input has been sent, send the next input rows, else wait for a fetch.
+int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
+  soda_hip_program* p = c.p;
+  const soda_hip_plan_t& plan = p->plan;
+  hipStream_t s_in = p->hstream[0], s_run = p->hstream[1], s_out = p->hstream[2];
+  const int ax = c.ax;
+  const int nb = (int)((c.rows + band_rows - 1) / band_rows);
+  const int64_t groups = (c.rows + c.chunk_rows - 1) / c.chunk_rows;
+  const int kBufs = 2;      // band output arrays per output, used in turn
+  // events: one per input row group, then per band buffer "computed" / "free"
+  if (int rc = make_events(&p->hevents, (size_t)groups + 2 * kBufs)) return rc;
+  hipEvent_t* ev_rows = p->hevents.data();
+  hipEvent_t* ev_run = ev_rows + groups;
+  hipEvent_t* ev_free = ev_run + kBufs;
+  if ((int)p->band_out.size() < kBufs * plan.num_outputs)
+    p->band_out.resize(kBufs * plan.num_outputs);
+  const int64_t buf_rows = band_rows + g_lo + g_hi;
+  for (int o = 0; o < plan.num_outputs; ++o)
+    for (int k = 0; k < kBufs; ++k)
+      if (int rc = ensure(p->band_out[o * kBufs + k],
+                          (size_t)buf_rows * c.plane *
+                              plan.elem_size[plan.num_inputs + o]))
+        return rc;
+
+  struct OutChunk {
+    int o, band;
+    int64_t a, b, origin;
+    bool first, last;      // of its band
+  };
+  std::vector<OutChunk> outq;
+  std::vector<int64_t> band_last(nb, -1);   // index of a band's last out chunk
+  int last_user[kBufs];                     // band that wrote a buffer last
+  for (int k = 0; k < kBufs; ++k) last_user[k] = -1;
+  int64_t gi = 0;          // next (input row group, input) unit to send
+  int bl = 0;              // next band to launch
+  size_t oi = 0, od = 0;   // out chunks: next to fetch, next to deliver
+
+  auto launch = [&](int b) -> int {
+    const int64_t r0 = (int64_t)b * band_rows;
+    const int64_t r1 = r0 + band_rows < c.rows ? r0 + band_rows : c.rows;
+    // rows of the band some output's valid box holds
+    const size_t before = outq.size();
+    for (int o = 0; o < plan.num_outputs; ++o) {
+      if (c.empty(o)) continue;
+      const int64_t a0 = r0 > c.lo(o)[ax] ? r0 : c.lo(o)[ax];
+      const int64_t b0 = r1 < c.hi(o)[ax] ? r1 : c.hi(o)[ax];
+      for (int64_t a = a0; a < b0; a += c.chunk_rows)
+        outq.push_back({o, b, a, a + c.chunk_rows < b0 ? a + c.chunk_rows : b0,
+                        0, false, false});
+    }
+    if (outq.size() == before) return SODA_HIP_OK;   // nothing to deliver
+    const int64_t gl = g_lo < r0 ? g_lo : r0;
+    const int64_t gh = g_hi < c.rows - r1 ? g_hi : c.rows - r1;
+    const int64_t origin_row = r0 - gl;
+    for (size_t k = before; k < outq.size(); ++k) outq[k].origin = origin_row;
+    outq[before].first = true;
+    outq.back().last = true;
+    band_last[b] = (int64_t)outq.size() - 1;
+    int32_t lext[SODA_HIP_MAX_DIM], origin[SODA_HIP_MAX_DIM],
+        gext[SODA_HIP_MAX_DIM];
+    for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+      lext[d] = d < c.dim ? c.extent[d] : 1;
+      gext[d] = lext[d];
+      origin[d] = 0;
+    }
+    lext[ax] = (int32_t)(r1 - r0 + gl + gh);
+    origin[ax] = (int32_t)origin_row;
+    std::vector<const void*> ins(c.in_ptrs);
+    for (int i = 0; i < plan.num_inputs; ++i)
+      ins[i] = static_cast<const char*>(c.in_ptrs[i]) +
+               (size_t)origin_row * c.plane * plan.elem_size[i];
+    std::vector<void*> outs(plan.num_outputs);
+    const int buf = b % kBufs;
+    for (int o = 0; o < plan.num_outputs; ++o)
+      outs[o] = p->band_out[o * kBufs + buf].ptr;
+    const int64_t need = (r1 + gh + c.chunk_rows - 1) / c.chunk_rows;
+    HIP_TRY(hipStreamWaitEvent(s_run, ev_rows[need - 1], 0));
+    if (p->hbuf_used[buf]) HIP_TRY(hipStreamWaitEvent(s_run, ev_free[buf], 0));
+    SlabRun slab;
+    memset(&slab, 0, sizeof slab);
+    slab.cone = {(int32_t)gl, (int32_t)(gl + r1 - r0), plan.reach_lo,
+                 plan.reach_hi};
+    // (scheduled by the model: a calibration per band extent would cost more
+    // than the bands save, and synchronise in the middle of the pipeline)
+    const bool was = p->calibrating;
+    p->calibrating = true;
+    const int rc = run_core(p, outs.data(), ins.data(), lext, origin, gext,
+                            c.iterate, s_run, -1, &slab);
+    p->calibrating = was;
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev_run[buf], s_run));
+    p->hbuf_used[buf] = true;
+    return SODA_HIP_OK;
+  };
+
+  for (int k = 0; k < kBufs; ++k) p->hbuf_used[k] = false;
+  // SODA_HIP_HOST_TRACE=1: where the host thread's time went, on stderr
+  const bool trace = getenv("SODA_HIP_HOST_TRACE") != nullptr;
+  double t_begin = now_ms(), t_send = 0, t_deliver = 0, t_launch = 0, t_wait = 0;
+  double t0 = 0;
+  for (;;) {
+    if (bl == nb && od == outq.size()) break;
+    // 1. a fetched chunk is there: write its part of the box
+    if (od < oi &&
+        hipEventQuery(p->ring_out.ev[od % c.slots]) == hipSuccess) {
+      const OutChunk& q = outq[od];
+      t0 = now_ms();
+      c.deliver(q.o, q.a, q.b, (int)(od % c.slots));
+      t_deliver += now_ms() - t0;
+      ++od;
+      continue;
+    }
+    (void)hipGetLastError();       // (hipErrorNotReady is not an error)
+    // 2. a slot is free: fetch the next chunk of a launched band
+    if (oi < outq.size() && oi - od < (size_t)c.slots) {
+      const OutChunk& q = outq[oi];
+      const int buf = q.band % kBufs;
+      if (q.first) HIP_TRY(hipStreamWaitEvent(s_out, ev_run[buf], 0));
+      if (int rc = c.fetch(q.o, q.a, q.b, p->band_out[q.o * kBufs + buf].ptr,
+                           q.origin, (int)(oi % c.slots), s_out))
+        return rc;
+      if (q.last) HIP_TRY(hipEventRecord(ev_free[buf], s_out));
+      ++oi;
+      continue;
+    }
+    // 3. the next band's input rows have been sent and its output array is
+    //    free (every fetch from its previous user enqueued): launch it
+    if (bl < nb) {
+      const int64_t r1 = (int64_t)(bl + 1) * band_rows < c.rows
+                             ? (int64_t)(bl + 1) * band_rows : c.rows;
+      const int64_t hi_row = r1 + g_hi < c.rows ? r1 + g_hi : c.rows;
+      const int64_t need = (hi_row + c.chunk_rows - 1) / c.chunk_rows;
+      const int user = last_user[bl % kBufs];
+      const bool buffer_free = user < 0 || band_last[user] < (int64_t)oi;
+      if (gi >= need * plan.num_inputs && buffer_free) {
+        t0 = now_ms();
+        if (int rc = launch(bl)) return rc;
+        t_launch += now_ms() - t0;
+        if (band_last[bl] >= 0) last_user[bl % kBufs] = bl;
+        ++bl;
+        continue;
+      }
+    }
+    // 4. send the next rows of the next input, if their slot is free (gi
+    //    counts (row group, input) units)
+    if (gi < groups * plan.num_inputs && c.can_send()) {
+      const int64_t g = gi / plan.num_inputs;
+      const int i = (int)(gi % plan.num_inputs);
+      const int64_t a = g * c.chunk_rows;
+      const int64_t b = a + c.chunk_rows < c.rows ? a + c.chunk_rows : c.rows;
+      t0 = now_ms();
+      if (int rc = c.send(i, a, b, s_in)) return rc;
+      if (i == plan.num_inputs - 1) HIP_TRY(hipEventRecord(ev_rows[g], s_in));
+      t_send += now_ms() - t0;
+      ++gi;
+      continue;
+    }
+    // 5. everything the host could do waits for a DMA (a slot of the input
+    //    ring, a fetch): look again in a moment
+    if (od < oi || gi < groups * plan.num_inputs) {
+      t0 = now_ms();
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+      t_wait += now_ms() - t0;
+      continue;
+    }
+    return fail(SODA_HIP_ERR_RUNTIME, "run_host: the band pipeline stalled");
+  }
+  if (trace)
+    fprintf(stderr, "soda_hip_run_host_box: %d bands of %lld rows, %lld-row "
+            "chunks: %.2f ms = send %.2f (pack + enqueue) + deliver %.2f + "
+            "launch %.2f + wait %.2f + other\n", nb, (long long)band_rows,
+            (long long)c.chunk_rows, now_ms() - t_begin, t_send, t_deliver,
+            t_launch, t_wait);
+  HIP_TRY(hipStreamSynchronize(s_in));
+  HIP_TRY(hipStreamSynchronize(s_run));
+  HIP_TRY(hipStreamSynchronize(s_out));
+  return SODA_HIP_OK;
+}
+
+}  // namespace
+
+}  // namespace soda_detail
+
+using namespace soda_detail;
+
+extern "C" {
+
+int soda_hip_host_copy_box(void* strided, const int32_t* stride, void* dense,
+                           const int32_t* extent, const int32_t* lo,
+                           const int32_t* hi, int32_t dim, int32_t elem,
+                           int32_t to_dense, int32_t row0, int32_t threads) {
+  if (!strided || !stride || !dense || !extent || !lo || !hi || dim < 1 ||
+      dim > SODA_HIP_MAX_DIM || elem < 1 || row0 < 0 || threads < 0)
+    return fail(SODA_HIP_ERR_INVALID, "host_copy_box: bad argument");
+  for (int d = 0; d < dim; ++d)
+    if (extent[d] < 1 || lo[d] < 0 || hi[d] > extent[d])
+      return fail(SODA_HIP_ERR_INVALID, "host_copy_box: box outside the array");
+  if (lo[dim - 1] < row0 && lo[dim - 1] < hi[dim - 1])
+    return fail(SODA_HIP_ERR_INVALID, "host_copy_box: box starts below row0");
+  copy_rows(static_cast<char*>(strided), stride, static_cast<char*>(dense),
+            extent, lo, hi, dim, elem, to_dense != 0, row0, threads);
+  return SODA_HIP_OK;
+}
+
+int soda_hip_run_host_box(soda_hip_program_t* p,
+                          const soda_hip_host_tensor_t* inputs,
+                          const soda_hip_host_tensor_t* outputs,
+                          int32_t iterate, const int32_t* valid_lo,
+                          const int32_t* valid_hi) {
+  if (!p || !inputs || !outputs)
+    return fail(SODA_HIP_ERR_INVALID, "run_host: NULL argument");
+  const soda_hip_plan_t& plan = p->plan;
+  if (iterate < 1) return fail(SODA_HIP_ERR_INVALID, "cannot iterate < 1 times");
+  HostCall c;
+  c.p = p;
+  c.inputs = inputs;
+  c.outputs = outputs;
+  c.iterate = iterate;
+  c.valid_lo = valid_lo;
+  c.valid_hi = valid_hi;
+  c.dim = plan.dim;
+  c.ax = plan.dim - 1;
+  c.extent = inputs[0].extent;
+  if (!c.extent) return fail(SODA_HIP_ERR_INVALID, "run_host: NULL extent");
+  c.cells = 1;
+  for (int d = 0; d < c.dim; ++d) {
+    if (c.extent[d] < 1)
+      return fail(SODA_HIP_ERR_INVALID, "run_host: extent < 1");
+    c.cells *= c.extent[d];
+  }
+  auto same_extent = [&](const soda_hip_host_tensor_t& t) {
+    if (!t.ptr || !t.extent || !t.stride) return false;
+    for (int d = 0; d < c.dim; ++d)
+      if (t.extent[d] != c.extent[d]) return false;
+    return true;
+  };
+  for (int i = 0; i < plan.num_inputs; ++i)
+    if (!same_extent(inputs[i]))
+      return fail(SODA_HIP_ERR_INVALID, "run_host: bad input tensor");
+  for (int o = 0; o < plan.num_outputs; ++o) {
+    if (!same_extent(outputs[o]))
+      return fail(SODA_HIP_ERR_INVALID, "run_host: bad output tensor");
+    for (int d = 0; d < c.dim; ++d)
+      if (c.lo(o)[d] < 0 || c.hi(o)[d] > c.extent[d])
+        return fail(SODA_HIP_ERR_INVALID, "run_host: box outside the array");
+  }
+  HIP_TRY(hipSetDevice(p->device));
+  for (int k = 0; k < 3; ++k)
+    if (!p->hstream[k])
+      HIP_TRY(hipStreamCreateWithFlags(&p->hstream[k], hipStreamNonBlocking));
+  c.rows = c.extent[c.ax];
+  c.plane = c.cells / c.rows;
+  int max_elem = 1;
+  for (int t = 0; t < plan.num_inputs + plan.num_outputs; ++t)
+    if (plan.elem_size[t] > max_elem) max_elem = plan.elem_size[t];
+  // rows per staged chunk: ~16 MiB of the widest tensor, the whole array if
+  // it is smaller
+  c.chunk_rows =
+      (int64_t)(chunk_target_bytes() / ((size_t)c.plane * max_elem));
+  if (c.chunk_rows < 1) c.chunk_rows = 1;
+  if (c.chunk_rows > c.rows) c.chunk_rows = c.rows;
+  c.slots = c.chunk_rows < c.rows ? HostRing::kMaxSlots : 1;
+  const size_t slot_bytes = (size_t)c.chunk_rows * c.plane * max_elem;
+  if (int rc = p->ring_in.ensure(slot_bytes, c.slots)) return rc;
+  if (int rc = p->ring_out.ensure(slot_bytes, c.slots)) return rc;
+  c.in_ptrs.resize(plan.num_inputs);
+  for (int i = 0; i < plan.num_inputs; ++i) {
+    if (int rc = ensure(p->host_in[i], (size_t)c.cells * plan.elem_size[i]))
+      return rc;
+    c.in_ptrs[i] = p->host_in[i].ptr;
+  }
+  const int prm0 = plan.num_inputs + plan.num_outputs + plan.num_locals;
+  for (int k = 0; k < plan.num_params; ++k) {
+    const soda_hip_host_tensor_t& t = inputs[plan.num_inputs + k];
+    if (!t.ptr) return fail(SODA_HIP_ERR_INVALID, "run_host: NULL param");
+    size_t bytes = (size_t)plan.param_elems[k] * plan.elem_size[prm0 + k];
+    if (int rc = ensure(p->host_prm[k], bytes)) return rc;
+    // (a few hundred bytes, pageable: staged by the time the call returns;
+    // first on the stream the input rows follow on)
+    HIP_TRY(hipMemcpyAsync(p->host_prm[k].ptr, t.ptr, bytes,
+                           hipMemcpyHostToDevice, p->hstream[0]));
+    c.in_ptrs.push_back(p->host_prm[k].ptr);
+  }
+  // Bands pay where copying dominates: ghost rows at most half a band (the
+  // kernels then do <= 1.5x the work), at least four bands.  A band is a whole
+  // number of staged chunks, two or more.
+  const char* bands_env = getenv("SODA_HIP_HOST_BANDS");
+  if (plan.has_reach && !(bands_env && !strcmp(bands_env, "0"))) {
+    const int64_t g_lo = (int64_t)iterate * plan.reach_lo;
+    const int64_t g_hi = (int64_t)iterate * plan.reach_hi;
+    int64_t per_band = (2 * (g_lo + g_hi) + c.chunk_rows - 1) / c.chunk_rows;
+    if (per_band < 2) per_band = 2;
+    const int64_t band_rows = per_band * c.chunk_rows;
+    if (band_rows * 4 <= c.rows + band_rows - 1)     // ceil(rows / band) >= 4
+      return run_banded(c, band_rows, g_lo, g_hi);
+  }
+  return run_whole(c);
+}
+
+int soda_hip_run_host(soda_hip_program_t* p,
+                      const soda_hip_host_tensor_t* inputs,
+                      const soda_hip_host_tensor_t* outputs, int32_t iterate) {
+  return soda_hip_run_host_box(p, inputs, outputs, iterate, nullptr, nullptr);
+}
+
+}  // extern "C"

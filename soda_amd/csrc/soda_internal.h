@@ -66,6 +66,18 @@ struct SlabRun {
   hipEvent_t sendable;          // may be null
 };
 
+// Pinned staging slots of the host-array entry (soda_host.cpp): chunk i + 1
+// is packed by worker threads while the DMA engine moves chunk i.
+struct HostRing {
+  static const int kMaxSlots = 4;
+  char* base = nullptr;
+  size_t slot_bytes = 0;
+  int slots = 0;
+  hipEvent_t ev[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int ensure(size_t slot_bytes, int slots);
+  void release();
+};
+
 }  // namespace soda_detail
 
 struct soda_hip_program {
@@ -78,6 +90,13 @@ struct soda_hip_program {
   std::vector<soda_detail::DeviceBuffer> host_in;  // run_host staging
   std::vector<soda_detail::DeviceBuffer> host_prm; // ... of the param arrays
   std::vector<soda_detail::DeviceBuffer> host_out;
+  // ... its streams (copies in / kernels / copies out), pinned slots, the
+  // band output arrays and events of the banded way (soda_host.cpp)
+  hipStream_t hstream[3] = {nullptr, nullptr, nullptr};
+  soda_detail::HostRing ring_in, ring_out;
+  std::vector<soda_detail::DeviceBuffer> band_out;
+  std::vector<hipEvent_t> hevents;
+  bool hbuf_used[2] = {false, false};
   int32_t last_launches = 0;
   int32_t last_fused = 0;
   int32_t last_split = 0;    // passes of the last run launched in two parts
@@ -134,6 +153,11 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
               const int32_t* extent, const int32_t* lo, const int32_t* hi,
               int dim, int elem, bool to_dense);
 bool is_dense(const soda_hip_host_tensor_t& t, int dim);
+// the same for a dense array that starts at index `row0` of the last
+// dimension, on up to `threads` threads (0: the pool's; soda_host.cpp)
+void copy_rows(char* strided, const int32_t* stride, char* dense,
+               const int32_t* extent, const int32_t* lo, const int32_t* hi,
+               int dim, int elem, bool to_dense, int32_t row0, int threads);
 
 }  // namespace soda_detail
 

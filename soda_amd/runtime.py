@@ -51,7 +51,7 @@ NAME_LEN = 96
 GROUP_NO_OVERLAP = 1
 GROUP_CALIBRATE = 2
 GROUP_THREADS = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class KernelDesc(ctypes.Structure):
@@ -92,7 +92,9 @@ class Plan(ctypes.Structure):
               ('num_kernels', ctypes.c_int32),
               ('kernels', KernelDesc * MAX_KERNELS),
               ('num_passes', ctypes.c_int32),
-              ('passes', PassDesc * MAX_PASSES)]
+              ('passes', PassDesc * MAX_PASSES),
+              ('has_reach', ctypes.c_int32), ('reach_lo', ctypes.c_int32),
+              ('reach_hi', ctypes.c_int32)]
 
 
 class StreamDesc(ctypes.Structure):
@@ -237,6 +239,9 @@ API = {
     'soda_hip_run_host_box': (ctypes.c_int, [
         _vp, ctypes.POINTER(HostTensor), ctypes.POINTER(HostTensor), _i32,
         _pi32, _pi32
+    ]),
+    'soda_hip_host_copy_box': (ctypes.c_int, [
+        _vp, _pi32, _vp, _pi32, _pi32, _pi32, _i32, _i32, _i32, _i32, _i32
     ]),
     'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),
     'soda_hip_program_set_debug_buffer': (ctypes.c_int, [_vp, _vp]),
@@ -484,6 +489,8 @@ def make_plan(mod: lower.Module,
     plan.passes[i].cost = 0.0    # marching passes carry a time model instead
     for j, k in enumerate(p.kernels):
       plan.passes[i].kernel[j] = k
+  plan.has_reach = 1
+  plan.reach_lo, plan.reach_hi = st.reach_along(st.dim - 1)
   return plan
 
 

@@ -499,6 +499,72 @@ def test_strided_host_arrays(built):
   assert not out_big[:, :8].any() and not out_big[:, 264:].any()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('kb', [8, 48])
+def test_host_entry_in_bands(built, monkeypatch, kb):
+  """soda_hip_run_host_box cut into bands along the last dimension (round 5,
+  soda_host.cpp run_banded): copy-in, kernels and copy-out of neighbouring
+  bands overlap on three streams, every band a window run with iterate x reach
+  ghost rows.  Forced onto small grids with staging chunks of a few KiB
+  (SODA_HIP_HOST_CHUNK_KB): the result must be the oracle's bit for bit on the
+  valid box and leave the rest of the caller's array alone -- 2-D and 3-D,
+  fused iterations, two coupled outputs, a preserved border, strided arrays
+  -- and equal the unbanded run (SODA_HIP_HOST_BANDS=0)."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  from oracle import c_oracle
+  monkeypatch.setenv('SODA_HIP_HOST_CHUNK_KB', str(kb))
+  cases = [
+      ('jacobi2d.soda', (512, 700), dict(iterate=7), (4,)),
+      ('blur.soda', (768, 400), {}, ()),
+      ('heat3d.soda', (64, 48, 160), dict(iterate=3), (2,)),
+      ('denoise2d.soda', (256, 600), {}, ()),
+      ('jacobi2d.soda', (256, 900), dict(iterate=5, border='preserve'), (4,)),
+      ('sobel2d.soda', (512, 333), {}, ()),
+  ]
+  rng = np.random.default_rng(11)
+  for name, extent, kw, fuse in cases:
+    st = core.from_file(soda_path(name), **kw)
+    shape = extent[::-1]
+    ins = {}
+    for n, t in zip(st.input_names, st.input_types):
+      dt = np.dtype(t.np_name)
+      ins[n] = (rng.random(shape).astype(dt) if dt.kind == 'f'
+                else rng.integers(0, 2000, shape).astype(dt))
+    want = c_oracle.COracle(st).run(ins)
+    runs = {}
+    for bands in ('1', '0'):
+      monkeypatch.setenv('SODA_HIP_HOST_BANDS', bands)
+      with runtime.Program(st, lower.LowerOptions(fuse=fuse),
+                           extent=extent) as prog:
+        # strided caller arrays: rows with a tail
+        big_in = {n: np.zeros(shape[:-1] + (shape[-1] + 24,), a.dtype)
+                  for n, a in ins.items()}
+        for n, a in ins.items():
+          big_in[n][..., 8:8 + shape[-1]] = a
+        outs_big = {n: np.full(shape[:-1] + (shape[-1] + 10,), 77,
+                               np.dtype(t.np_name))
+                    for n, t in zip(st.output_names, st.output_types)}
+        outs = {n: a[..., 3:3 + shape[-1]] for n, a in outs_big.items()}
+        prog.run({n: a[..., 8:8 + shape[-1]] for n, a in big_in.items()},
+                 outputs=outs)
+        runs[bands] = {n: a.copy() for n, a in outs_big.items()}
+    for o in st.output_names:
+      assert np.array_equal(runs['1'][o].view(np.uint8),
+                            runs['0'][o].view(np.uint8)), (name, o)
+      got = runs['1'][o][..., 3:3 + shape[-1]]
+      if st.preserve_border:
+        idx = tuple(slice(None) for _ in shape)
+      else:
+        lo, hi = st.valid_box(extent, o)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      assert np.array_equal(got[idx].view(np.uint8),
+                            want[o][idx].view(np.uint8)), (name, o, kb)
+      mask = np.ones(runs['1'][o].shape, bool)
+      mask[..., 3:3 + shape[-1]][idx] = False
+      assert (runs['1'][o][mask] == 77).all(), (name, o, 'outside the box')
+
+
 def test_device_entry_and_errors(built):
   from soda_amd import core, runtime, util
   from soda_amd.codegen.hip import lower

@@ -131,3 +131,72 @@ def test_wire_kernel_links_under_a_reference_style_host(built, tmp_path):
                        timeout=300)
   assert run.returncode == 0 and run.stdout.startswith('OK'), (
       run.stdout + run.stderr)
+
+
+def _copy_box(lib, strided, dense, extent, lo, hi, to_dense, row0, threads):
+  import ctypes
+  import numpy as np
+  dim = len(extent)
+  item = strided.dtype.itemsize
+  i32 = lambda v: (ctypes.c_int32 * dim)(*v)            # noqa: E731
+  strides = [s // item for s in strided.strides[::-1]]
+  base = strided.ctypes.data
+  rc = lib.soda_hip_host_copy_box(
+      ctypes.c_void_p(base), i32(strides), ctypes.c_void_p(dense.ctypes.data),
+      i32(extent), i32(lo), i32(hi), dim, item, int(to_dense), row0, threads)
+  assert rc == 0
+
+
+@pytest.mark.parametrize('threads', [1, 0])
+def test_pack_and_unpack_of_the_host_entry(built, threads):
+  """soda_hip_host_copy_box (soda_host.cpp): the pack / unpack step of
+  soda_hip_run_host_box -- the reference's scatter and gather loops,
+  frt/host.py:181-249,340-427 -- on the calling thread and on the worker pool,
+  against numpy slicing: dense and strided arrays, 1 to 4 dimensions, whole
+  arrays and inner boxes, staging arrays that start at a row > 0; cells outside
+  the box keep what they held."""
+  import numpy as np
+  from soda_amd import runtime
+  lib = runtime.library()
+  rng = np.random.default_rng(7)
+  cases = [
+      # extent (dim 0 first), dtype, lo, hi, row0
+      ((5000,), np.float32, (0,), (5000,), 0),
+      ((3000000,), np.uint8, (17,), (2999990,), 5),         # one long line
+      ((700, 900), np.float32, (0, 0), (700, 900), 0),       # > 2 MiB: the pool
+      ((700, 900), np.float32, (3, 100), (690, 870), 100),
+      ((64, 48, 96), np.uint16, (1, 2, 10), (60, 40, 90), 7),
+      ((1024, 32, 40), np.float64, (0, 0, 0), (1024, 32, 40), 0),
+      ((16, 8, 6, 5), np.int16, (1, 1, 1, 1), (15, 7, 5, 4), 1),
+  ]
+  for extent, dt, lo, hi, row0 in cases:
+    shape = extent[::-1]
+    dim = len(extent)
+    for layout in ('dense', 'padded', 'every-other'):
+      if layout == 'dense':
+        backing = rng.integers(0, 250, shape).astype(dt)
+        arr = backing
+      elif layout == 'padded':            # rows with a tail, stride[0] = 1
+        backing = rng.integers(0, 250, shape[:-1] + (shape[-1] + 13,)).astype(dt)
+        arr = backing[..., :shape[-1]]
+      else:                               # stride[0] = 2
+        backing = rng.integers(0, 250, shape[:-1] + (2 * shape[-1],)).astype(dt)
+        arr = backing[..., ::2]
+      rows = extent[-1] - row0
+      box = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      # pack: strided -> dense (rows from row0 on)
+      stage = np.full((rows,) + shape[1:], 251, dtype=dt)
+      _copy_box(lib, arr, stage, extent, lo, hi, True, row0, threads)
+      want = np.full_like(stage, 251)
+      sbox = (slice(lo[-1] - row0, hi[-1] - row0),) + box[1:]
+      want[sbox] = arr[box]
+      assert np.array_equal(stage, want), (extent, layout, 'pack')
+      # unpack: dense -> strided, nothing outside the box written
+      src = rng.integers(0, 250, stage.shape).astype(dt)
+      before = backing.copy()
+      _copy_box(lib, arr, src, extent, lo, hi, False, row0, threads)
+      expect = before.copy()
+      view = expect if layout == 'dense' else (
+          expect[..., :shape[-1]] if layout == 'padded' else expect[..., ::2])
+      view[box] = src[sbox]
+      assert np.array_equal(backing, expect), (extent, layout, 'unpack')
