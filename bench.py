@@ -92,6 +92,9 @@ def parse_args():
                   help='upper bound of the untimed spin in front of the timed '
                   'region (steps until two 10-step windows agree within 1 %%)')
   ap.add_argument('--no-single-iter', action='store_true')
+  ap.add_argument('--no-other-configs', action='store_true',
+                  help='skip BASELINE configs C3 / C4 / C5 (measured after '
+                  'the timed region, ~2 s)')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='target CPU time of the cpu_baseline sample')
   return ap.parse_args()
@@ -211,6 +214,103 @@ def rehearse(args, stencil, extent, fuses, options, stream, value_1gpu):
                  'at the speed of the middle rank\'s slab measured on this '
                  'GPU; compute only')
   return out
+
+
+def other_configs(stream):
+  """BASELINE.json's other single-GPU configurations on this GPU, measured
+  AFTER the timed region (the reference's host prints throughput
+  for every run it makes, frt/host.py:324-335; until now only C2 was in the
+  driver's line): C3 blur 16384^2 (fused two-stage, u16), C4 heat3d 512^3 x 50
+  on one GPU, C5 jacobi2d 8192^2 x 1000 -- inputs resident, the whole run
+  between HIP events on the launch stream, then the dominant pass alone for
+  its roofline fraction.  Parity of these configs at full size is the GPU test
+  suite's (tests/test_baseline_configs.py, test_hip_parity.py), not this
+  leg's."""
+  import torch
+  from soda_amd import core, isa, runtime
+  from soda_amd.codegen.hip import lower
+  soda = os.path.join(ROOT, 'tests', 'golden', 'soda')
+  tdt = {'float32': torch.float32, 'uint16': torch.int16,
+         'int16': torch.int16}
+  rows = []
+  for label, name, extent, iterate, fuse, reps in (
+      ('C3', 'blur.soda', (16384, 16384), 1, (), 10),
+      ('C4', 'heat3d.soda', (512, 512, 512), 50, (2,), 3),
+      ('C5', 'jacobi2d.soda', (8192, 8192), 1000, lower.DEFAULT_FUSE, 2)):
+    row = {'config': label, 'workload': '%s %s iterate=%d' % (
+        name[:-5], 'x'.join(map(str, extent)), iterate)}
+    try:
+      st = core.from_file(os.path.join(soda, name), iterate=iterate)
+      shape = tuple(extent[::-1])
+      ins = []
+      for t in st.input_types:
+        dt = tdt[t.np_name]
+        ins.append(torch.rand(shape, device='cuda', dtype=dt)
+                   if dt.is_floating_point else
+                   torch.randint(0, 30000, shape, device='cuda', dtype=dt))
+      outs = [torch.empty(shape, device='cuda', dtype=tdt[t.np_name])
+              for t in st.output_types]
+      table = st.symbol_table
+      bpc = (sum(table[n].size_in_bytes for n in st.input_names) +
+             sum(table[n].size_in_bytes for n in st.output_names))
+      cells = 1
+      for e in extent:
+        cells *= e
+      with runtime.Program(st, lower.LowerOptions(fuse=fuse), extent=extent,
+                           calibrate=True) as prog:
+
+        def go(iters=iterate):
+          prog.run_device([t.data_ptr() for t in outs],
+                          [t.data_ptr() for t in ins], extent, iterate=iters,
+                          stream=stream)
+
+        go()
+        torch.cuda.synchronize()
+        ms = time_events(go, stream, reps)
+        launches = prog.last_launches()[0]
+        sched = prog.schedule(extent, iterate)
+        us = prog.pass_times(extent)[0]
+        depth = max(sched, key=lambda t: sched[t] * us.get(t, float(t)))
+        n = min(8, max(1, iterate // depth))
+        while n > 1 and prog.schedule(extent, depth * n) != {depth: n}:
+          n -= 1
+        kernel_ms = None
+        if prog.schedule(extent, depth * n) == {depth: n}:
+          go(depth * n)
+          kernel_ms = time_events(lambda: go(depth * n), stream,
+                                  max(1, 16 // n)) / n
+        ps = [p for p in prog.module.sorted_passes() if p.fused_iters == depth]
+        kname = prog.module.kernels[ps[0].kernels[0]].name
+        row.update({
+            'ms': ms, 'value': cells * iterate / (ms * 1e-3),
+            'unit': 'cells*iters/s', 'launches': launches,
+            'schedule': {str(t): c for t, c in sched.items()},
+            'dtype': str(table[st.input_names[0]]),
+            'kernel': kname, 'isa_key': isa.isa_key(prog.code, kname),
+            'kernel_family': ps[0].kind, 'iterations_per_launch': depth,
+            'kernel_ms': kernel_ms,
+        })
+        if kernel_ms:
+          ach = cells * bpc / (kernel_ms * 1e-3) / 1e9
+          row['roofline'] = {'bound': 'hbm', 'achieved': ach,
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': ach / HBM_PEAK_GBS,
+                             'algorithmic_bytes_per_launch': cells * bpc}
+          try:
+            st_k = isa.module_static(prog.module, prog.code,
+                                     prog.geometry(extent)[0],
+                                     extent).get(kname)
+          except Exception:     # noqa: BLE001
+            st_k = None
+          if st_k:
+            row['roofline']['valu_frac'] = st_k['min_issue_ms'] / kernel_ms
+            if row['roofline']['valu_frac'] > row['roofline']['frac']:
+              row['roofline']['bound'] = 'valu'
+      del ins, outs
+    except Exception as e:        # a side measurement must not take the bench down
+      row['error'] = '%s: %s' % (type(e).__name__, str(e)[:200])
+    rows.append(row)
+  return rows
 
 
 def group_main(args):
@@ -656,38 +756,81 @@ def main():
     roofline['measured_copy_GBs'] = None
     roofline['measured_copy_error'] = str(e)[:200]
   # PMC traffic is collected in separate rocprofv3 passes (tools/
-  # profile_round.sh) and kept in profiles/traffic.json under the content key
-  # of the kernel module it was measured on: a number taken on another build of
-  # the kernel -- same name, other code -- is dropped, not reported
+  # profile_round.sh) and kept in profiles/traffic.json under the key of the
+  # KERNEL it was measured on -- a hash of that kernel's machine code and
+  # descriptor (soda_amd/isa.py; until round 4 the key covered the whole module
+  # source, so an edit to a helper orphaned every number).  A number taken on
+  # other code under the same name is dropped, not reported.
+  from soda_amd import isa
   kernel_key = runtime.source_key(prog.module.source)
   roofline['kernel_key'] = kernel_key
+  roofline['isa_key'] = isa.isa_key(prog.code, kname)
+  roofline['compiler'] = runtime.compiler_version()
+  # vector-ALU wave-instructions per launch counted from the code object
+  # (straight-line prologue + loop body x trips, over the launch geometry):
+  # the second roof of a temporally blocked stencil, present with or without
+  # a PMC pass
+  static = {}
+  try:
+    static = isa.module_static(prog.module, prog.code,
+                               prog.geometry(local_extent)[0], local_extent)
+  except Exception as e:   # a measurement aid must not take the bench down
+    roofline['static_error'] = '%s: %s' % (type(e).__name__, str(e)[:160])
+
+  def valu_roof(name, ms, pmc_insts=None):
+    st = static.get(name)
+    if not st:
+      return None
+    out = {
+        'wave_instructions_per_launch': st['valu_per_launch'],
+        'min_issue_ms': st['min_issue_ms'],
+        'frac_of_valu_issue_peak': st['min_issue_ms'] / ms if ms else None,
+        'per_row_step': {k: st['%s_per_row_step' % k]
+                         for k in ('valu', 'dpp', 'lds_crossbar', 'vmem_load',
+                                   'vmem_store', 'waitcnt')},
+        'source': 'static: llvm-objdump of the code object, loop body x trips '
+                  'over the launch geometry (soda_amd/isa.py); peak = 1024 '
+                  'SIMDs x 2.4 GHz / 2 cycles per wave64 instruction',
+    }
+    if pmc_insts:
+      out['measured_wave_instructions_per_launch'] = pmc_insts
+      out['static_over_measured'] = st['valu_per_launch'] / pmc_insts
+    return out
+
+  def pmc_of(name, key):
+    """The counter entry of profiles/traffic.json for `name`, if it was taken
+    on this very machine code (else None and why)."""
+    entry = traffic_table.get(name)
+    if not entry:
+      return None, None
+    if entry.get('isa_key'):
+      if entry['isa_key'] == key:
+        return entry, None
+      return None, ('profiles/traffic.json holds %s for machine code %s; this '
+                    'run built %s' % (name, entry['isa_key'], key))
+    if entry.get('kernel_key') == kernel_key:     # (files of rounds 1-4)
+      return entry, None
+    return None, ('profiles/traffic.json holds %s for module key %s; this run '
+                  'built %s' % (name, entry.get('kernel_key'), kernel_key))
+
   traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
   traffic_table = {}
   if os.path.exists(traffic_file):
     try:
       with open(traffic_file) as f:
-        measured = traffic_table = json.load(f)
-      if kname in measured and measured[kname].get('kernel_key') != kernel_key:
-        roofline['traffic_dropped'] = (
-            'profiles/traffic.json holds %s for key %s; this run built key %s'
-            % (kname, measured[kname].get('kernel_key'), kernel_key))
-      elif kname in measured:
-        roofline['traffic'] = measured[kname]['hbm_bytes_per_launch']
-        roofline['traffic_source'] = measured[kname].get('source')
-        insts = measured[kname].get('valu_wave_instructions_per_launch')
-        if insts:
-          # second roof of a temporally blocked stencil: VALU issue.  A wave64
-          # VALU op holds a SIMD for 2 cycles at best (tools/valubench.py);
-          # 1024 SIMDs at the 2.4 GHz peak clock.
-          issue_s = insts * 2.0 / (1024 * 2.4e9)
-          roofline['valu'] = {
-              'wave_instructions_per_launch': insts,
-              'min_issue_ms': issue_s * 1e3,
-              'frac_of_valu_issue_peak': issue_s * 1e3 / kernel_ms,
-              'source': 'rocprofv3 --pmc SQ_INSTS_VALU (profiles/traffic.json)',
-          }
-    except (OSError, ValueError, KeyError):
-      pass
+        traffic_table = json.load(f)
+    except (OSError, ValueError):
+      traffic_table = {}
+  pmc, why = pmc_of(kname, roofline['isa_key'])
+  if why:
+    roofline['traffic_dropped'] = why
+  if pmc and pmc.get('hbm_bytes_per_launch'):
+    roofline['traffic'] = pmc['hbm_bytes_per_launch']
+    roofline['traffic_source'] = pmc.get('source')
+  v = valu_roof(kname, kernel_ms,
+                (pmc or {}).get('valu_wave_instructions_per_launch'))
+  if v:
+    roofline['valu'] = v
 
   launches_per_step = 0
   overlap_trial = None
@@ -830,21 +973,37 @@ def main():
     ms = kernel_ms if depth == fuse else time_pass(depth)
     ps = [p for p in prog.module.sorted_passes() if p.fused_iters == depth]
     name = prog.module.kernels[ps[0].kernels[0]].name if ps else '?'
-    pmc = traffic_table.get(name) or {}
+    key = isa.isa_key(prog.code, name)
+    pmc_k, _ = pmc_of(name, key)
+    vk = valu_roof(name, ms, (pmc_k or {}).get(
+        'valu_wave_instructions_per_launch'))
     scheduled.append({
-        'kernel': name,
-        'traffic': pmc.get('hbm_bytes_per_launch')
-                   if pmc.get('kernel_key') == kernel_key else None,
+        'kernel': name, 'isa_key': key,
+        'traffic': (pmc_k or {}).get('hbm_bytes_per_launch'),
         'iterations_per_launch': depth,
         'launches_per_exchange_interval': count,
         'kernel_ms': ms,
         'frac': alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
+        **({'valu_frac': vk['frac_of_valu_issue_peak'],
+            'valu_wave_instructions_per_launch':
+                vk['wave_instructions_per_launch']} if vk else {}),
     })
   torch.cuda.synchronize()
   roofline['scheduled_kernels'] = scheduled
   if 'valu' in roofline:
     roofline['valu']['frac_of_valu_issue_peak'] = (
         roofline['valu']['min_issue_ms'] / kernel_ms)
+    # which roof the launch is nearer to.  `achieved` / `peak` / `frac` stay
+    # the HBM figures of the contract (algorithmic bytes / duration); a fused
+    # kernel that sits nearer its VALU-issue roof says so here
+    if roofline['valu']['frac_of_valu_issue_peak'] > roofline['frac']:
+      roofline['bound'] = 'valu'
+      roofline['bound_frac'] = roofline['valu']['frac_of_valu_issue_peak']
+      roofline['bound_note'] = (
+          'VALU issue: %.3g wave-instructions per launch need %.1f us at peak '
+          'issue; `frac` is the HBM fraction of the same launch' %
+          (roofline['valu']['wave_instructions_per_launch'],
+           roofline['valu']['min_issue_ms'] * 1e3))
 
   cells = 1
   for e in extent:
@@ -983,6 +1142,7 @@ def main():
           'unit': 'cells*iters/s', 'ms_per_step': ms,
           'kernel': prog1.module.kernels[0].name,
           'kernel_key': runtime.source_key(prog1.module.source),
+          'isa_key': isa.isa_key(prog1.code, prog1.module.kernels[0].name),
           'roofline': {'bound': 'hbm', 'achieved': k1, 'peak': HBM_PEAK_GBS,
                        'unit': 'GB/s', 'frac': k1 / HBM_PEAK_GBS,
                        'frac_of_measured_copy':
@@ -990,6 +1150,8 @@ def main():
                            if roofline.get('measured_copy_GBs') else None},
       }
       prog1.close()
+    if not args.no_other_configs and emulate <= 1:
+      result['other_configs'] = other_configs(stream)
     if not args.no_rehearsal and emulate <= 1:
       result['rehearsed_scaling'] = rehearse(args, stencil, extent, fuses,
                                              options, stream, value)

@@ -1539,6 +1539,7 @@ class _MarchKernel:
                              warm_saved=saved,
                              lane_redundancy=64.0 / self.strip_lanes,
                              peel_trips=self.peeled // self.U,
+                             unroll=self.U, tile_rows=self.tile_rows,
                              peel_trips_max=self.peel_trips_max,
                              fused=self.T,
                              window_extra=(self.m_hi - self.m_lo) if self.buf else None,

@@ -98,8 +98,15 @@ SODA_DEV int soda_dpp_shl1_or(int v, int edge) {
 // (v_add_f32_dpp; the generator defines SODA_FOLD_F32_DPP for them): it is what
 // the hot jacobi/heat kernels rely on, and every such program of the suites is
 // bit-exact with it.
+//
+// SODA_UNGUARDED_OPAQUE / _WIDE / _OWN switch ONE of the three compiler-fault
+// workarounds of this file off (tests/test_compiler_pins.py builds each
+// fault's reproducer that way to record whether the installed compiler still
+// needs it; never defined in a product build).
 SODA_DEV int soda_opaque(int v) {
+#ifndef SODA_UNGUARDED_OPAQUE
   asm volatile("" : "+v"(v));
+#endif
   return v;
 }
 
@@ -114,7 +121,9 @@ SODA_DEV int soda_opaque(int v) {
 template <class T>
 SODA_DEV int soda_wide(T v) {
   int w = (int)v;
+#ifndef SODA_UNGUARDED_WIDE
   asm volatile("" : "+v"(w));
+#endif
   return w;
 }
 
@@ -122,8 +131,14 @@ SODA_DEV int soda_wide(T v) {
 // the value passes through an empty asm the compiler cannot see through)
 template <class T, int V>
 SODA_DEV void soda_own_register(T (&v)[V]) {
+#ifndef SODA_UNGUARDED_OWN
 #pragma unroll
-  for (int e = 0; e < V; ++e) v[e] = (T)soda_opaque((int)v[e]);
+  for (int e = 0; e < V; ++e) {
+    int w = (int)v[e];
+    asm volatile("" : "+v"(w));
+    v[e] = (T)w;
+  }
+#endif
 }
 
 template <class T, int kSize = sizeof(T), bool kFloat = __is_floating_point(T)>

@@ -180,9 +180,7 @@ def static_profile(instrs) -> Dict[str, Dict[str, int]]:
   """Instruction counts of one kernel by region: `pre` (entry to the head of
   its innermost-outermost loop, executed once by a live wave), `loop` (one
   trip of the body), `post`.  The marching kernels have exactly one loop (the
-  unrolled row-step loop); a kernel without a backward branch is all `pre`.
-  `exit_at`: instructions an out-of-range wave executes before its early
-  return (the first forward branch that leaves the kernel's body)."""
+  unrolled row-step loop); a kernel without a backward branch is all `pre`."""
   loops = [(t, a) for a, m, _, t in instrs if t is not None and t <= a]
   if not loops:
     return {'pre': _count(instrs), 'loop': {'total': 0}, 'post': {'total': 0},
@@ -229,3 +227,35 @@ def march_valu_per_launch(profile: Dict[str, Dict[str, int]],
     trips = max(0, -(-(rows + warm - peeled_steps) // unroll))
     total += waves * (pre + trips * loop)
   return total
+
+
+def module_static(module, code: bytes, tiles: Dict[str, Sequence[int]],
+                  extent: Sequence[int]) -> Dict[str, dict]:
+  """{kernel name: static counts} for the marching kernels of a lowered module
+  (`module`: codegen.hip.module.Module, `code`: its code object, `tiles`:
+  {kernel: block tile} the library uses on `extent` -- Program.geometry):
+  wave-instructions per launch by class, per row step of the loop, the key of
+  the kernel's machine code, and the VALU-issue floor of a launch."""
+  dis = disassemble(code)
+  dim = module.stencil.dim
+  out = {}
+  for k in module.kernels:
+    tune = k.tune or {}
+    if 'axis' not in tune or k.name not in dis or k.name not in tiles:
+      continue
+    if tune.get('waves_per_block', 1) != 1 or tune.get('pipe', 1) != 1:
+      continue          # (blocks of several waves: not modelled here)
+    prof = static_profile(dis[k.name])
+    unroll = int(tune.get('unroll') or 1)
+    peeled = int(tune.get('peel_trips') or 0) * unroll
+    warm = int(tune.get('warm') or 0)
+    entry = {'isa_key': isa_key(code, k.name), 'loop_row_steps': unroll,
+             'loops': prof['loops']}
+    for kind in ('valu', 'dpp', 'lds_crossbar', 'vmem_load', 'vmem_store',
+                 'waitcnt', 'salu'):
+      entry['%s_per_launch' % kind] = march_valu_per_launch(
+          prof, extent, tiles[k.name], dim, warm, peeled, unroll, kind)
+      entry['%s_per_row_step' % kind] = prof['loop'].get(kind, 0) / float(unroll)
+    entry['min_issue_ms'] = entry['valu_per_launch'] / VALU_PEAK_PER_S * 1e3
+    out[k.name] = entry
+  return out

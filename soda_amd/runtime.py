@@ -19,7 +19,10 @@ from soda_amd import core, util
 from soda_amd.codegen.hip import lower
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsoda_hip.so')
+# SODA_HIP_LIBRARY: another build of the same sources -- the sanitizer builds
+# of `make -C soda_amd/csrc asan tsan` (tools/sanitize.sh), never a substitute
+LIB_PATH = os.environ.get('SODA_HIP_LIBRARY') or \
+    os.path.join(_HERE, 'libsoda_hip.so')
 CACHE_DIR = os.environ.get('SODA_HIP_CACHE',
                            os.path.join(_HERE, '_jit_cache'))
 ARCH = 'gfx950'
@@ -844,16 +847,19 @@ class Program:
   def __init__(self, stencil: core.Stencil,
                opts: Optional[lower.LowerOptions] = None, device: int = 0,
                extent: Optional[Sequence[int]] = None,
-               calibrate: Optional[bool] = None):
+               calibrate: Optional[bool] = None,
+               source_prefix: str = ''):
     """`calibrate`: True -- time the passes on `extent` now; None (default) --
     the library does it by itself on the first run of an extent (a few ms,
     once; soda_hip_program_set_auto_calibrate); False -- never: runs are
-    scheduled by the model."""
+    scheduled by the model.  `source_prefix`: text compiled in front of the
+    module (diagnostic builds only: tests/test_compiler_pins.py switches a
+    compiler-fault workaround of soda_rt.h off with a #define)."""
     self.stencil = stencil
     self.opts = resolve_options(stencil, opts, extent)   # never the caller's
     self.device = device
     self.module = lower.lower(stencil, self.opts)
-    self.code = compile_source(self.module.source,
+    self.code = compile_source(source_prefix + self.module.source,
                                '%s.hip' % stencil.app_name)
     self.resources = kernel_resources(self.code)
     # launch geometry (chunk lengths, pass schedule) is the library's, decided

@@ -418,3 +418,101 @@ def test_sliding_sum_setup_with_lds_pipe_shifts_compiles(built, shift, tmp_path)
   mod = lower.lower(stencil, opts)
   assert 'xa_t0_w0_r0' in mod.source
   assert runtime.compile_source(mod.source, 'w.hip', cache_dir=str(tmp_path))
+
+
+def test_counter_evidence_is_for_the_kernels_head_builds(built):
+  """profiles/traffic.json (PMC bytes and VALU counts bench.py reports as
+  `roofline.traffic` / checks `roofline.valu` against) names, per kernel, the
+  hash of the machine code it was measured on (soda_amd/isa.py isa_key).  The
+  default bench module lowered and compiled HERE must carry the same keys --
+  else the driver's bench line would drop the evidence as it did in round 4
+  (`traffic: null` after a late soda_rt.h edit).  A red test means: run
+  tools/profile_round.sh on the GPU box again and commit profiles/traffic.json
+  as the round's last act."""
+  import json
+  from soda_amd import core, isa, runtime
+  from soda_amd.codegen.hip import lower
+  path = os.path.join(ROOT, 'profiles', 'traffic.json')
+  with open(path) as f:
+    table = json.load(f)
+  st = core.from_file(soda_path('jacobi2d.soda'), iterate=100)
+  extent = (8192, 8192)
+  opts = runtime.resolve_options(st, lower.LowerOptions(fuse=lower.DEFAULT_FUSE),
+                                 extent)
+  mod = lower.lower(st, opts)
+  code = runtime.compile_source(mod.source, '%s.hip' % st.app_name)
+  plan = runtime.make_plan(mod, runtime.kernel_resources(code))
+  keyed = {n: e for n, e in table.items() if e.get('isa_key')}
+  if not keyed:
+    pytest.skip('profiles/traffic.json predates per-kernel keys (rounds 1-4)')
+  if runtime.compiler_version() not in {e.get('compiler') for e in
+                                        keyed.values()}:
+    pytest.skip('another compiler than the evidence was taken with')
+  # (which passes a step runs is the CLOCK's choice on the GPU box -- 4 x T13 +
+  # 4 x T12 on 8192^2 -- so: every kernel of the module that the table holds
+  # must match, and the deepest pass, which every schedule uses, must be there)
+  names = [k.name for k in mod.kernels]
+  deepest = mod.kernels[mod.sorted_passes()[0].kernels[0]].name
+  assert deepest in keyed, (
+      '%s is what HEAD builds for the deepest pass but profiles/traffic.json '
+      'has no counters for it: re-run tools/profile_round.sh' % deepest)
+  # (the one-iteration kernel's name is shared with the module of bench.py's
+  # single_iter leg, other code under the same name: the fused kernels only)
+  fused = {k.name for k in mod.kernels if (k.tune or {}).get('fused', 1) > 1}
+  scheduled = [n for n in names if n in keyed and n in fused]
+  for name in scheduled:
+    assert keyed[name]['isa_key'] == isa.isa_key(code, name), (
+        'profiles/traffic.json was measured on other machine code of %s: '
+        're-run tools/profile_round.sh as the last GPU act' % name)
+    assert keyed[name].get('hbm_bytes_per_launch', 0) > 0
+  # and the static count agrees with the counter where both exist
+  tiles, _ = runtime.plan_geometry(plan, extent)
+  static = isa.module_static(mod, code, {k.name: t for k, t in
+                                         zip(mod.kernels, tiles)}, extent)
+  for name in scheduled:
+    pmc = keyed[name].get('valu_wave_instructions_per_launch')
+    if pmc and name in static:
+      assert abs(static[name]['valu_per_launch'] / pmc - 1) < 0.02, (
+          name, static[name]['valu_per_launch'], pmc)
+
+
+def test_static_valu_count_of_the_benched_kernels(built):
+  """soda_amd/isa.py on the default bench module, no GPU: every fused kernel
+  has exactly one loop, issues ~20 VALU instructions per 4 cells per fused
+  iteration in it (5 per cell: four adds and a multiply -- the arithmetic
+  floor; the lane shifts ride on the adds as DPP modifiers or run on the LDS
+  pipe), and the per-launch count lands where round 4's SQ_INSTS_VALU
+  counters did (T13: 9.97e7, T12: 8.74e7)."""
+  from soda_amd import core, isa, runtime
+  from soda_amd.codegen.hip import lower
+  if isa.objdump() is None:
+    pytest.skip('llvm-objdump not installed')
+  st = core.from_file(soda_path('jacobi2d.soda'), iterate=100)
+  extent = (8192, 8192)
+  opts = runtime.resolve_options(st, lower.LowerOptions(fuse=lower.DEFAULT_FUSE),
+                                 extent)
+  mod = lower.lower(st, opts)
+  code = runtime.compile_source(mod.source, '%s.hip' % st.app_name)
+  plan = runtime.make_plan(mod, runtime.kernel_resources(code))
+  tiles, _ = runtime.plan_geometry(plan, extent)
+  static = isa.module_static(mod, code, {k.name: t for k, t in
+                                         zip(mod.kernels, tiles)}, extent)
+  assert len(static) == len(mod.kernels)
+  for k in mod.kernels:
+    s = static[k.name]
+    depth = k.tune['fused']
+    assert s['loops'] == 1 and s['isa_key']
+    per_level = s['valu_per_row_step'] / depth
+    assert 20.0 <= per_level <= (27.0 if depth == 1 else 21.5), (k.name,
+                                                                  per_level)
+    if depth >= 8:      # mixh: one DPP and one swizzle per level and row step
+      assert s['dpp_per_row_step'] == depth
+      assert s['lds_crossbar_per_row_step'] == depth
+  t13 = [s for n, s in static.items() if '_T13_' in n][0]
+  t12 = [s for n, s in static.items() if '_T12_' in n][0]
+  assert abs(t13['valu_per_launch'] / 9.97e7 - 1) < 0.03
+  assert abs(t12['valu_per_launch'] / 8.74e7 - 1) < 0.03
+  # two kernels of one module have different keys; the key is stable
+  assert t13['isa_key'] != t12['isa_key']
+  assert t13['isa_key'] == isa.isa_key(code, [n for n in static
+                                              if '_T13_' in n][0])

@@ -200,3 +200,73 @@ def test_pack_and_unpack_of_the_host_entry(built, threads):
           expect[..., :shape[-1]] if layout == 'padded' else expect[..., ::2])
       view[box] = src[sbox]
       assert np.array_equal(backing, expect), (extent, layout, 'unpack')
+
+
+WIRE_HOSTS = [
+    # main, program (None: blur with two banks per tensor), first word of stdout
+    ('jacobi2d_wire_main.cpp', 'jacobi2d.soda'),
+    ('heat3d_wire_main.cpp', 'heat3d.soda'),
+    ('blur_banks_wire_main.cpp', None),
+]
+
+
+def _two_bank_blur(tmp_path):
+  text = open(soda_path('blur.soda')).read()
+  text = text.replace('input dram 0 uint16', 'input dram 0.1 uint16')
+  text = text.replace('output dram 1 uint16', 'output dram 2.3 uint16')
+  assert 'dram 0.1' in text and 'dram 2.3' in text
+  path = os.path.join(str(tmp_path), 'blur_banks.soda')
+  with open(path, 'w') as f:
+    f.write(text)
+  return path
+
+
+@pytest.mark.parametrize('main,soda', WIRE_HOSTS)
+def test_independent_wire_hosts_against_the_kernel_contract(tmp_path, main,
+                                                            soda):
+  """The three reference-style callers (tests/host/frt_host.h: the reference
+  host's sizes, scatter, call and gather transcribed from its text, no import
+  of anything of this repository) against a plain CPU statement of the kernel
+  contract (tests/host/cpu_stream_kernels.cpp), under ASan + UBSan: their
+  layout arithmetic and closed-form expectations hold before a GPU is asked
+  -- four tiles of jacobi2d as shipped, 2 x 2 tiles of heat3d, two banks per
+  tensor."""
+  exe = os.path.join(str(tmp_path), 'host_cpu')
+  host = os.path.join(ROOT, 'tests', 'host')
+  subprocess.run(['g++', '-std=c++17', '-O1', '-Wall', '-Werror',
+                  '-fsanitize=address,undefined', os.path.join(host, main),
+                  os.path.join(host, 'cpu_stream_kernels.cpp'), '-o', exe],
+                 check=True)
+  run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+  assert run.returncode == 0 and run.stdout.startswith('OK'), (
+      run.stdout + run.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('main,soda', WIRE_HOSTS)
+def test_wire_kernels_under_independent_hosts(built, tmp_path, main, soda):
+  """`sodac --hip-wire-kernel` definitions of
+  jacobi2d_kernel (iterate 2, tile 32, four tiles), heat3d_kernel (3-D tiles)
+  and a two-bank blur_kernel, each linked under a caller written from the
+  reference host's text alone and checked against a closed form -- no Python
+  in the process, no layout constant shared with soda_amd.stream."""
+  path = _two_bank_blur(tmp_path) if soda is None else soda_path(soda)
+  src = os.path.join(str(tmp_path), 'wire.cpp')
+  subprocess.run([sys.executable, '-m', 'soda_amd.sodac', path,
+                  '--hip-wire-kernel', src], cwd=ROOT, check=True)
+  if soda is None:
+    assert ('void* bank_0_blur_y, void* bank_1_blur_y, void* bank_0_input, '
+            'void* bank_1_input, uint64_t coalesced_data_num') in \
+        open(src).read()
+  exe = os.path.join(str(tmp_path), 'wire_host')
+  libdir = os.path.join(ROOT, 'soda_amd')
+  subprocess.run(['g++', '-std=c++17', '-O1', '-DSODA_CPP_BINDING', src,
+                  os.path.join(ROOT, 'tests', 'host', main),
+                  '-I', os.path.join(ROOT, 'include'), '-L', libdir,
+                  '-lsoda_hip', '-Wl,-rpath,' + libdir, '-o', exe], check=True)
+  env = dict(os.environ)
+  env['LD_LIBRARY_PATH'] = '/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
+  run = subprocess.run([exe], capture_output=True, text=True, env=env,
+                       timeout=300)
+  assert run.returncode == 0 and run.stdout.startswith('OK'), (
+      run.stdout + run.stderr)

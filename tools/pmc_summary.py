@@ -69,24 +69,28 @@ def main():
       entry['gui_active_cycles_per_xcd'] = (
           sum(v['GRBM_GUI_ACTIVE']) / len(v['GRBM_GUI_ACTIVE']) / 8)
     result[name] = entry
-  # tie every measurement to the build of the kernel it was taken on: bench.py
-  # reports the content key of the module it JIT-built (roofline.kernel_key)
-  # and drops a traffic figure whose key differs from its own
+  # tie every measurement to the KERNEL it was taken on: bench.py reports, per
+  # kernel, a hash of its machine code + descriptor (isa_key, soda_amd/isa.py)
+  # and drops a traffic figure whose key differs from what it built (the
+  # module-source key of rounds 1-4 is kept beside it)
   if len(sys.argv) > 6:
     with open(sys.argv[6]) as f:
       line = [l for l in f.read().splitlines() if l.startswith('{')][-1]
     bench = json.loads(line)
     roof = bench['roofline']
-    # the step's passes live in one module (one key); the single-iteration leg
-    # builds its own
-    pairs = [(k.get('kernel'), roof.get('kernel_key'))
-             for k in roof.get('scheduled_kernels', [])]
-    pairs.append((roof.get('kernel'), roof.get('kernel_key')))
+    triples = [(k.get('kernel'), k.get('isa_key'), roof.get('kernel_key'))
+               for k in roof.get('scheduled_kernels', [])]
+    triples.append((roof.get('kernel'), roof.get('isa_key'),
+                    roof.get('kernel_key')))
     si = bench.get('single_iter') or {}
-    pairs.append((si.get('kernel'), si.get('kernel_key')))
-    for name, key in pairs:
-      if name in result and key:
-        result[name]['kernel_key'] = key
+    triples.append((si.get('kernel'), si.get('isa_key'), si.get('kernel_key')))
+    for name, isa_key, key in triples:
+      if name in result:
+        if isa_key:
+          result[name]['isa_key'] = isa_key
+        if key:
+          result[name]['kernel_key'] = key
+        result[name]['compiler'] = roof.get('compiler')
   with open(out_json, 'w') as f:
     json.dump(result, f, indent=1, sort_keys=True)
   print(json.dumps(result, indent=1, sort_keys=True))
