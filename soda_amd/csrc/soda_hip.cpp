@@ -1526,7 +1526,13 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
   if (!s || !out_banks || !in_banks)
     return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL argument");
   const soda_hip_stream_desc_t& d = s->desc;
-  HIP_TRY(hipSetDevice(s->linear.back()->device));
+  // The banks are the generated host's pageable `aligned_alloc` buffers
+  // (ref frt/host.py:165-178): they travel through the pinned rings and the
+  // worker threads of the host-array entry (soda_host.cpp), on one stream with
+  // the kernels, instead of synchronous pageable copies.
+  soda_hip_program* owner = s->linear.back();
+  hipStream_t stream = nullptr;
+  if (int rc = host_stream(owner, &stream)) return rc;
   int total = 0;
   for (int t = 0; t < d.num_inputs + d.num_outputs; ++t) total += d.banks[t];
   s->host_banks.resize(total);
@@ -1540,8 +1546,9 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
       if (!in_banks[bank])
         return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL input bank");
       if (int rc = ensure(s->host_banks[slot], bytes)) return rc;
-      HIP_TRY(hipMemcpy(s->host_banks[slot].ptr, in_banks[bank], bytes,
-                        hipMemcpyHostToDevice));
+      if (int rc = ring_send(owner, s->host_banks[slot].ptr, in_banks[bank],
+                             bytes, stream))
+        return rc;
       dev_in.push_back(s->host_banks[slot].ptr);
     }
   std::vector<size_t> out_bytes;
@@ -1554,16 +1561,17 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
       dev_out.push_back(s->host_banks[slot].ptr);
       out_bytes.push_back(bytes);
     }
-  if (int rc = soda_hip_stream_run_device(s, dev_out.data(), dev_in.data(),
-                                          coalesced_data_num, nullptr))
-    return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  for (size_t k = 0; k < dev_out.size(); ++k) {
+  for (size_t k = 0; k < dev_out.size(); ++k)
     if (!out_banks[k])
       return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL output bank");
-    HIP_TRY(hipMemcpy(out_banks[k], dev_out[k], out_bytes[k],
-                      hipMemcpyDeviceToHost));
-  }
+  if (int rc = soda_hip_stream_run_device(s, dev_out.data(), dev_in.data(),
+                                          coalesced_data_num, stream))
+    return rc;
+  for (size_t k = 0; k < dev_out.size(); ++k)
+    if (int rc = ring_fetch(owner, out_banks[k], dev_out[k], out_bytes[k],
+                            stream))
+      return rc;
+  HIP_TRY(hipStreamSynchronize(stream));
   return SODA_HIP_OK;
 }
 

@@ -202,9 +202,19 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
 }
 
 // ---- the ring of pinned staging slots -------------------------------------------
+int HostRing::wait(int slot) {
+  if (busy[slot]) {
+    HIP_TRY(hipEventSynchronize(ev[slot]));
+    busy[slot] = false;
+  }
+  return SODA_HIP_OK;
+}
+
 int HostRing::ensure(size_t want_slot_bytes, int want_slots) {
   if (base && slot_bytes >= want_slot_bytes && slots >= want_slots)
     return SODA_HIP_OK;
+  for (int i = 0; i < slots; ++i)      // nothing in flight on memory we free
+    if (int rc = wait(i)) return rc;
   release();
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&base),
                         want_slot_bytes * want_slots, hipHostMallocDefault));
@@ -225,6 +235,7 @@ void HostRing::release() {
   base = nullptr;
   slot_bytes = 0;
   slots = 0;
+  for (bool& b : busy) b = false;
 }
 
 namespace {
@@ -272,7 +283,6 @@ struct HostCall {
   int slots;
   int32_t zero[SODA_HIP_MAX_DIM] = {0, 0, 0, 0};
   std::vector<const void*> in_ptrs;     // device: inputs, then params
-  bool in_used[HostRing::kMaxSlots] = {false, false, false, false};
   int in_turn = 0;
 
   const int32_t* lo(int o) const { return valid_lo ? valid_lo + o * dim : zero; }
@@ -281,8 +291,11 @@ struct HostCall {
   // is the slot the next send() packs into free (its last DMA done)?
   bool can_send() {
     const int sl = in_turn % slots;
-    if (!in_used[sl]) return true;
-    if (hipEventQuery(p->ring_in.ev[sl]) == hipSuccess) return true;
+    if (!p->ring_in.busy[sl]) return true;
+    if (hipEventQuery(p->ring_in.ev[sl]) == hipSuccess) {
+      p->ring_in.busy[sl] = false;
+      return true;
+    }
     (void)hipGetLastError();       // (hipErrorNotReady is not an error)
     return false;
   }
@@ -291,7 +304,7 @@ struct HostCall {
   int send(int i, int64_t a, int64_t b, hipStream_t stream) {
     const int elem = p->plan.elem_size[i];
     const int sl = in_turn++ % slots;
-    if (in_used[sl]) HIP_TRY(hipEventSynchronize(p->ring_in.ev[sl]));
+    if (int rc = p->ring_in.wait(sl)) return rc;
     char* slot = p->ring_in.base + (size_t)sl * p->ring_in.slot_bytes;
     int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
     for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
@@ -307,7 +320,7 @@ struct HostCall {
                            slot, (size_t)(b - a) * plane * elem,
                            hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(p->ring_in.ev[sl], stream));
-    in_used[sl] = true;
+    p->ring_in.busy[sl] = true;
     return SODA_HIP_OK;
   }
 
@@ -323,6 +336,7 @@ struct HostCall {
                            (size_t)(b - a) * plane * elem,
                            hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(p->ring_out.ev[sl], stream));
+    p->ring_out.busy[sl] = true;
     return SODA_HIP_OK;
   }
 
@@ -384,7 +398,7 @@ int run_whole(HostCall& c) {
       if (d >= 0) {
         const int64_t a = r0 + d * c.chunk_rows;
         const int64_t b = a + c.chunk_rows < r1 ? a + c.chunk_rows : r1;
-        HIP_TRY(hipEventSynchronize(p->ring_out.ev[d % c.slots]));
+        if (int rc = p->ring_out.wait((int)(d % c.slots))) return rc;
         c.deliver(o, a, b, (int)(d % c.slots));
       }
     }
@@ -504,6 +518,7 @@ int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
     // 1. a fetched chunk is there: write its part of the box
     if (od < oi &&
         hipEventQuery(p->ring_out.ev[od % c.slots]) == hipSuccess) {
+      p->ring_out.busy[od % c.slots] = false;
       const OutChunk& q = outq[od];
       t0 = now_ms();
       c.deliver(q.o, q.a, q.b, (int)(od % c.slots));
@@ -579,6 +594,79 @@ int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
 }
 
 }  // namespace
+
+// Contiguous host bytes -> device through the program's input ring: chunk i + 1
+// is copied into its pinned slot by the worker threads while chunk i is on the
+// link.  Returns with the last DMAs in flight on `stream`.
+int ring_send(soda_hip_program* p, void* dev, const void* host, size_t bytes,
+              hipStream_t stream) {
+  if (!bytes) return SODA_HIP_OK;
+  const size_t target = chunk_target_bytes();
+  const size_t chunk = bytes < target ? bytes : target;
+  const int slots = chunk < bytes ? HostRing::kMaxSlots : 1;
+  if (int rc = p->ring_in.ensure(chunk, slots)) return rc;
+  const int32_t one = 1;
+  int turn = 0;
+  for (size_t off = 0; off < bytes; off += chunk, ++turn) {
+    const size_t n = off + chunk < bytes ? chunk : bytes - off;
+    const int sl = turn % slots;
+    if (int rc = p->ring_in.wait(sl)) return rc;   // (also a previous call's DMA)
+    char* slot = p->ring_in.base + (size_t)sl * p->ring_in.slot_bytes;
+    const int32_t ext = (int32_t)n, lo = 0;
+    copy_rows(const_cast<char*>(static_cast<const char*>(host)) + off, &one,
+              slot, &ext, &lo, &ext, 1, 1, true, 0, 0);
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(dev) + off, slot, n,
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(p->ring_in.ev[sl], stream));
+    p->ring_in.busy[sl] = true;
+  }
+  return SODA_HIP_OK;
+}
+
+// Device bytes -> contiguous host memory through the output ring; returns
+// when every byte has been delivered.
+int ring_fetch(soda_hip_program* p, void* host, const void* dev, size_t bytes,
+               hipStream_t stream) {
+  if (!bytes) return SODA_HIP_OK;
+  const size_t target = chunk_target_bytes();
+  const size_t chunk = bytes < target ? bytes : target;
+  const int slots = chunk < bytes ? HostRing::kMaxSlots : 1;
+  if (int rc = p->ring_out.ensure(chunk, slots)) return rc;
+  const int32_t one = 1;
+  const int64_t nchunk = (int64_t)((bytes + chunk - 1) / chunk);
+  for (int64_t c = 0; c < nchunk + slots - 1; ++c) {
+    if (c < nchunk) {
+      const size_t off = (size_t)c * chunk;
+      const size_t n = off + chunk < bytes ? chunk : bytes - off;
+      const int sl = (int)(c % slots);
+      HIP_TRY(hipMemcpyAsync(p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes,
+                             static_cast<const char*>(dev) + off, n,
+                             hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(p->ring_out.ev[sl], stream));
+      p->ring_out.busy[sl] = true;
+    }
+    const int64_t d = c - (slots - 1);
+    if (d >= 0) {
+      const size_t off = (size_t)d * chunk;
+      const size_t n = off + chunk < bytes ? chunk : bytes - off;
+      const int sl = (int)(d % slots);
+      if (int rc = p->ring_out.wait(sl)) return rc;
+      const int32_t ext = (int32_t)n, lo = 0;
+      copy_rows(static_cast<char*>(host) + off, &one,
+                p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes, &ext,
+                &lo, &ext, 1, 1, false, 0, 0);
+    }
+  }
+  return SODA_HIP_OK;
+}
+
+int host_stream(soda_hip_program* p, hipStream_t* stream) {
+  HIP_TRY(hipSetDevice(p->device));
+  if (!p->hstream[0])
+    HIP_TRY(hipStreamCreateWithFlags(&p->hstream[0], hipStreamNonBlocking));
+  *stream = p->hstream[0];
+  return SODA_HIP_OK;
+}
 
 }  // namespace soda_detail
 

@@ -74,7 +74,11 @@ struct HostRing {
   size_t slot_bytes = 0;
   int slots = 0;
   hipEvent_t ev[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+  // a DMA out of / into the slot may still be in flight (its event recorded):
+  // whoever fills the slot next waits for the event first
+  bool busy[kMaxSlots] = {false, false, false, false};
   int ensure(size_t slot_bytes, int slots);
+  int wait(int slot);      // until the slot's last DMA is done
   void release();
 };
 
@@ -158,6 +162,15 @@ bool is_dense(const soda_hip_host_tensor_t& t, int dim);
 void copy_rows(char* strided, const int32_t* stride, char* dense,
                const int32_t* extent, const int32_t* lo, const int32_t* hi,
                int dim, int elem, bool to_dense, int32_t row0, int threads);
+
+// contiguous host <-> device copies through a program's pinned rings and the
+// worker pool (soda_host.cpp); ring_fetch returns when the bytes are delivered
+int ring_send(soda_hip_program* p, void* dev, const void* host, size_t bytes,
+              hipStream_t stream);
+int ring_fetch(soda_hip_program* p, void* host, const void* dev, size_t bytes,
+               hipStream_t stream);
+// the program's stream of host-array runs, made on first use
+int host_stream(soda_hip_program* p, hipStream_t* stream);
 
 }  // namespace soda_detail
 

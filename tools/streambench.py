@@ -16,6 +16,8 @@ def main():
   ap.add_argument('--soda', default='tests/golden/soda/blur.soda')
   ap.add_argument('--extent', type=int, nargs='+', default=[2000, 16384])
   ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--host', action='store_true',
+                  help='also time soda_hip_stream_run_host on pageable banks')
   args = ap.parse_args()
   from soda_amd import core, runtime, stream
   st = core.from_file(args.soda)
@@ -56,6 +58,29 @@ def main():
                       'mode': prog.last_mode, 'ms_per_call': round(ms, 4),
                       'cells_iters_per_s': cells * st.iterate / ms * 1e3,
                       'tiles': lay.tiles}))
+    if args.host:
+      # <app>_kernel on HOST banks, as the generated host calls it
+      # (SODA_CPP_BINDING): pageable arrays of the reference's sizes
+      import numpy as np
+      import time
+      hin = {n: [np.ones(lay.buf_elems[n] // lay.bank_count[n],
+                         np.dtype(table[n].np_name))
+                 for _ in range(lay.bank_count[n])] for n in st.input_names}
+      hout = {n: [np.zeros(lay.buf_elems[n] // lay.bank_count[n],
+                           np.dtype(table[n].np_name))
+                  for _ in range(lay.bank_count[n])] for n in st.output_names}
+      prog.run_banked_host(hout, hin, lay.cycle_count)
+      ts = []
+      for _ in range(3):
+        t0 = time.perf_counter()
+        prog.run_banked_host(hout, hin, lay.cycle_count)
+        ts.append((time.perf_counter() - t0) * 1e3)
+      nbytes = sum(a.nbytes for v in list(hin.values()) + list(hout.values())
+                   for a in v)
+      print(json.dumps({'soda': os.path.basename(args.soda), 'mode': prog.last_mode,
+                        'host_banks_ms_per_call': round(min(ts), 3),
+                        'bytes_moved': nbytes,
+                        'GBs': nbytes / (min(ts) * 1e-3) / 1e9}))
     prog.close()
 
 
