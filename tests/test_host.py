@@ -266,7 +266,15 @@ def test_wire_kernels_under_independent_hosts(built, tmp_path, main, soda):
                   '-lsoda_hip', '-Wl,-rpath,' + libdir, '-o', exe], check=True)
   env = dict(os.environ)
   env['LD_LIBRARY_PATH'] = '/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
-  run = subprocess.run([exe], capture_output=True, text=True, env=env,
-                       timeout=300)
-  assert run.returncode == 0 and run.stdout.startswith('OK'), (
-      run.stdout + run.stderr)
+  # the banks travel through the pinned staging ring (soda_host.cpp ring_send /
+  # ring_fetch): once whole (one slot per bank, re-used bank after bank -- the
+  # stress run of round 5 caught the second bank overwriting the first one's
+  # slot while its DMA was in flight), once in 16 KiB chunks (all four slots)
+  for chunk_kb in (None, '16'):
+    env.pop('SODA_HIP_HOST_CHUNK_KB', None)
+    if chunk_kb:
+      env['SODA_HIP_HOST_CHUNK_KB'] = chunk_kb
+    run = subprocess.run([exe], capture_output=True, text=True, env=env,
+                         timeout=300)
+    assert run.returncode == 0 and run.stdout.startswith('OK'), (
+        chunk_kb, run.stdout + run.stderr)
