@@ -656,10 +656,11 @@ int soda_hip_group_load(soda_hip_group_t* g,
                         const soda_hip_host_tensor_t* inputs) {
   if (!g || !inputs) return fail(SODA_HIP_ERR_INVALID, "group_load: NULL argument");
   const soda_hip_plan_t& plan = g->plan;
-  const int dim = plan.dim, ax = dim - 1;
+  const int dim = plan.dim;
   if (int rc = soda_hip_group_synchronize(g)) return rc;
-  int64_t cells = g->row_cells * g->desc.extent[ax];
-  std::vector<char> staging;
+  // every slab's rows (ghost rows included) through that slab's pinned ring,
+  // packed by the worker threads while the previous chunk -- or the previous
+  // slab's last chunks, on another GPU's link -- is in flight (soda_host.cpp)
   for (int t = 0; t < plan.num_inputs; ++t) {
     const soda_hip_host_tensor_t& h = inputs[t];
     if (!h.ptr || !h.extent || !h.stride)
@@ -668,23 +669,19 @@ int soda_hip_group_load(soda_hip_group_t* g,
       if (h.extent[i] != g->desc.extent[i])
         return fail(SODA_HIP_ERR_INVALID,
                     "group_load: a tensor's extent is not the group's");
-    const int elem = plan.elem_size[t];
-    const char* host = static_cast<const char*>(h.ptr);
-    if (!is_dense(h, dim)) {
-      int32_t zero[SODA_HIP_MAX_DIM] = {0, 0, 0, 0};
-      staging.resize((size_t)cells * elem);
-      copy_box(static_cast<char*>(h.ptr), h.stride, staging.data(),
-               g->desc.extent, zero, g->desc.extent, dim, elem, true);
-      host = staging.data();
-    }
-    const int64_t row_bytes = g->row_cells * elem;
     for (auto& s : g->slabs) {
-      HIP_TRY(hipSetDevice(s->device));
-      HIP_TRY(hipMemcpy(g->inputs_of(*s, g->interval)[t],
-                        host + (int64_t)s->begin * row_bytes,
-                        (size_t)(s->end - s->begin) * row_bytes,
-                        hipMemcpyHostToDevice));
+      hipStream_t stream = nullptr;
+      if (int rc = host_stream(s->prog, &stream)) return rc;
+      if (int rc = send_rows(s->prog, h, g->desc.extent, dim, plan.elem_size[t],
+                             s->begin, s->end,
+                             g->inputs_of(*s, g->interval)[t], s->begin, stream))
+        return rc;
     }
+  }
+  for (auto& s : g->slabs) {
+    hipStream_t stream = nullptr;
+    if (int rc = host_stream(s->prog, &stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
   }
   const int prm0 = plan.num_inputs + plan.num_outputs + plan.num_locals;
   for (int k = 0; k < plan.num_params; ++k) {
@@ -806,11 +803,9 @@ int soda_hip_group_store(soda_hip_group_t* g,
   if (!g || !outputs)
     return fail(SODA_HIP_ERR_INVALID, "group_store: NULL argument");
   const soda_hip_plan_t& plan = g->plan;
-  const int dim = plan.dim, ax = dim - 1;
+  const int dim = plan.dim;
   if (int rc = soda_hip_group_synchronize(g)) return rc;
-  int64_t cells = g->row_cells * g->desc.extent[ax];
   int32_t zero[SODA_HIP_MAX_DIM] = {0, 0, 0, 0};
-  std::vector<char> staging;
   for (int o = 0; o < plan.num_outputs; ++o) {
     const soda_hip_host_tensor_t& h = outputs[o];
     if (!h.ptr || !h.extent || !h.stride)
@@ -820,32 +815,20 @@ int soda_hip_group_store(soda_hip_group_t* g,
         return fail(SODA_HIP_ERR_INVALID,
                     "group_store: a tensor's extent is not the group's");
     const int elem = plan.elem_size[plan.num_inputs + o];
-    const int64_t row_bytes = g->row_cells * elem;
     const int32_t* lo = valid_lo ? valid_lo + o * dim : zero;
     const int32_t* hi = valid_hi ? valid_hi + o * dim : g->desc.extent;
-    bool whole = true;
-    for (int i = 0; i < dim; ++i)
-      whole = whole && lo[i] == 0 && hi[i] == g->desc.extent[i];
-    const bool direct = whole && is_dense(h, dim);
-    char* dense = static_cast<char*>(h.ptr);
-    if (!direct) {
-      staging.resize((size_t)cells * elem);
-      dense = staging.data();
-    }
+    // only the valid box reaches the caller's array (frt/host.py:357-375):
+    // every slab's own rows of it, through the slab's pinned ring
     for (auto& s : g->slabs) {
       const void* result = g->iterable ? g->inputs_of(*s, g->interval)[o]
                                        : s->side[1][o];
-      HIP_TRY(hipSetDevice(s->device));
-      HIP_TRY(hipMemcpy(dense + (int64_t)s->own_begin * row_bytes,
-                        static_cast<const char*>(result) +
-                            (int64_t)(s->own_begin - s->begin) * row_bytes,
-                        (size_t)(s->own_end - s->own_begin) * row_bytes,
-                        hipMemcpyDeviceToHost));
+      hipStream_t stream = nullptr;
+      if (int rc = host_stream(s->prog, &stream)) return rc;
+      if (int rc = fetch_rows(s->prog, h, g->desc.extent, lo, hi, dim, elem,
+                              s->own_begin, s->own_end, result, s->begin,
+                              stream))
+        return rc;
     }
-    // only the valid box reaches the caller's array (frt/host.py:357-375)
-    if (!direct)
-      copy_box(static_cast<char*>(h.ptr), h.stride, staging.data(),
-               g->desc.extent, lo, hi, dim, elem, false);
   }
   return SODA_HIP_OK;
 }

@@ -660,6 +660,107 @@ int ring_fetch(soda_hip_program* p, void* host, const void* dev, size_t bytes,
   return SODA_HIP_OK;
 }
 
+namespace {
+
+int64_t rows_per_chunk(int64_t plane_bytes, int64_t rows) {
+  int64_t n = (int64_t)(chunk_target_bytes() / (size_t)(plane_bytes > 0 ? plane_bytes : 1));
+  if (n < 1) n = 1;
+  return n > rows ? rows : n;
+}
+
+}  // namespace
+
+// Rows [a, b) (last dimension) of a host tensor of `extent`, dense or strided
+// -> device memory holding the dense array from row `dev_row0` on: packed chunk
+// by chunk into p's input ring by the worker threads while the previous chunk
+// is on the link.  Returns with the last DMAs in flight on `stream`.
+int send_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
+              const int32_t* extent, int dim, int elem, int64_t a, int64_t b,
+              void* dev, int64_t dev_row0, hipStream_t stream) {
+  if (b <= a) return SODA_HIP_OK;
+  const int ax = dim - 1;
+  int64_t plane = 1;
+  for (int d = 0; d < ax; ++d) plane *= extent[d];
+  const int64_t step = rows_per_chunk(plane * elem, b - a);
+  const int slots = step < b - a ? HostRing::kMaxSlots : 1;
+  if (int rc = p->ring_in.ensure((size_t)step * plane * elem, slots)) return rc;
+  int turn = 0;
+  for (int64_t r = a; r < b; r += step, ++turn) {
+    const int64_t e = r + step < b ? r + step : b;
+    const int sl = turn % slots;
+    if (int rc = p->ring_in.wait(sl)) return rc;
+    char* slot = p->ring_in.base + (size_t)sl * p->ring_in.slot_bytes;
+    int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
+    for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+      l[d] = 0;
+      h[d] = d < dim ? extent[d] : 1;
+    }
+    l[ax] = (int32_t)r;
+    h[ax] = (int32_t)e;
+    copy_rows(static_cast<char*>(t.ptr), t.stride, slot, extent, l, h, dim, elem,
+              true, (int32_t)r, 0);
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(dev) +
+                               (size_t)(r - dev_row0) * plane * elem,
+                           slot, (size_t)(e - r) * plane * elem,
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(p->ring_in.ev[sl], stream));
+    p->ring_in.busy[sl] = true;
+  }
+  return SODA_HIP_OK;
+}
+
+// The part of box [lo, hi) that lies in rows [a, b): device array (dense, from
+// row `dev_row0` on) -> the host tensor, nothing outside the box written; the
+// DMA runs up to four chunks ahead of the threads that unpack.  Returns when
+// everything is delivered.
+int fetch_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
+               const int32_t* extent, const int32_t* lo, const int32_t* hi,
+               int dim, int elem, int64_t a, int64_t b, const void* dev,
+               int64_t dev_row0, hipStream_t stream) {
+  const int ax = dim - 1;
+  if (a < lo[ax]) a = lo[ax];
+  if (b > hi[ax]) b = hi[ax];
+  for (int d = 0; d < dim; ++d)
+    if (hi[d] <= lo[d]) return SODA_HIP_OK;
+  if (b <= a) return SODA_HIP_OK;
+  int64_t plane = 1;
+  for (int d = 0; d < ax; ++d) plane *= extent[d];
+  const int64_t step = rows_per_chunk(plane * elem, b - a);
+  const int slots = step < b - a ? HostRing::kMaxSlots : 1;
+  if (int rc = p->ring_out.ensure((size_t)step * plane * elem, slots)) return rc;
+  const int64_t nchunk = (b - a + step - 1) / step;
+  for (int64_t c = 0; c < nchunk + slots - 1; ++c) {
+    if (c < nchunk) {
+      const int64_t r = a + c * step, e = r + step < b ? r + step : b;
+      const int sl = (int)(c % slots);
+      HIP_TRY(hipMemcpyAsync(p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes,
+                             static_cast<const char*>(dev) +
+                                 (size_t)(r - dev_row0) * plane * elem,
+                             (size_t)(e - r) * plane * elem,
+                             hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(p->ring_out.ev[sl], stream));
+      p->ring_out.busy[sl] = true;
+    }
+    const int64_t d = c - (slots - 1);
+    if (d >= 0) {
+      const int64_t r = a + d * step, e = r + step < b ? r + step : b;
+      const int sl = (int)(d % slots);
+      if (int rc = p->ring_out.wait(sl)) return rc;
+      int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
+      for (int k = 0; k < SODA_HIP_MAX_DIM; ++k) {
+        l[k] = k < dim ? lo[k] : 0;
+        h[k] = k < dim ? hi[k] : 1;
+      }
+      l[ax] = (int32_t)r;
+      h[ax] = (int32_t)e;
+      copy_rows(static_cast<char*>(t.ptr), t.stride,
+                p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes, extent,
+                l, h, dim, elem, false, (int32_t)r, 0);
+    }
+  }
+  return SODA_HIP_OK;
+}
+
 int host_stream(soda_hip_program* p, hipStream_t* stream) {
   HIP_TRY(hipSetDevice(p->device));
   if (!p->hstream[0])

@@ -169,6 +169,16 @@ int ring_send(soda_hip_program* p, void* dev, const void* host, size_t bytes,
               hipStream_t stream);
 int ring_fetch(soda_hip_program* p, void* host, const void* dev, size_t bytes,
                hipStream_t stream);
+// rows [a, b) of a host tensor -> device / the part of box [lo, hi) in rows
+// [a, b) of a device array -> a host tensor, through the rings (soda_host.cpp);
+// `dev` holds the dense array from row `dev_row0` of the last dimension on
+int send_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
+              const int32_t* extent, int dim, int elem, int64_t a, int64_t b,
+              void* dev, int64_t dev_row0, hipStream_t stream);
+int fetch_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
+               const int32_t* extent, const int32_t* lo, const int32_t* hi,
+               int dim, int elem, int64_t a, int64_t b, const void* dev,
+               int64_t dev_row0, hipStream_t stream);
 // the program's stream of host-array runs, made on first use
 int host_stream(soda_hip_program* p, hipStream_t* stream);
 
