@@ -230,7 +230,7 @@ def default_prefetch(fused_iters: int, lane_shift: str = 'dpp') -> int:
   153 at 4; with 'mixh' shifts, 11 registers leaner: 149.6 at 2, 136.2 at 4)."""
   if fused_iters <= 2:
     return 8
-  if fused_iters <= 8 or lane_shift == 'mixh':
+  if fused_iters <= 8 or lane_shift in ('mixh', 'mix64', 'mix64d'):
     return 4
   return 2
 

@@ -199,6 +199,8 @@ class MarchConfig:
                     '_swz' if self.lane_shift == 'swz' else
                     '_swzh' if self.lane_shift == 'swzh' else
                     '_mixh' if self.lane_shift == 'mixh' else
+                    '_mix64' if self.lane_shift == 'mix64' else
+                    '_mix64d' if self.lane_shift == 'mix64d' else
                     '_ldsx' if self.lane_shift == 'lds' else
                     '_noshift' if self.lane_shift == 'none' else '') + (
                         '_mw%d' % self.min_waves if self.min_waves else '') + (
@@ -798,7 +800,13 @@ class _MarchKernel:
     # 'mixh': the two shift directions on two different pipes -- down through
     # DPP (vector ALU), up through ds_swizzle (the LDS crossbar, shared by the
     # four SIMDs of a CU) -- on half strips, as 'swzh'
-    self.use_mix = self.cfg.lane_shift == 'mixh'
+    # 'mix64' / 'mix64d' (round 5 experiment): the same split on WHOLE 64-lane
+    # strips -- the DPP wave shift crosses the halves by itself, the swizzle
+    # rotates within 32 lanes and the one lane that must cross is patched
+    # (v_readlane + v_writelane / one DPP move restricted to lanes 28-31): 56
+    # of 64 lanes valid at T = 13 instead of 48, for 2 / 1 more instructions
+    # per fused iteration and row step
+    self.use_mix = self.cfg.lane_shift in ('mixh', 'mix64', 'mix64d')
     # Integer sums over a run of taps along the STREAMED dimension as a sliding
     # sum: an int32 accumulator per cell that lives across row steps,
     #     acc += newest row;  result = cast(acc);  acc -= oldest row
@@ -1180,8 +1188,9 @@ class _MarchKernel:
         elif self.use_swz or (self.use_mix and lane_off > 0):
           expr = src
           for _ in range(abs(lane_off)):
-            expr = 'soda_lane_%s%d(%s)' % ('dn' if lane_off < 0 else 'up',
-                                           self.group, expr)
+            expr = 'soda_lane_%s%d%s(%s)' % (
+                'dn' if lane_off < 0 else 'up', self.group,
+                'd' if self.cfg.lane_shift == 'mix64d' else '', expr)
         else:
           expr = src
           for _ in range(abs(lane_off)):

@@ -359,6 +359,17 @@ struct soda_swz<T, 2> {   // widened: one VGPR per element
 };
 template <class T>
 struct soda_swz<T, 1> : soda_swz<T, 2> {};
+// up-shift of a whole 64-lane strip with the crossing lane patched by ONE DPP
+// move: wave_shl:1 restricted to row 1, bank 3 (lanes 28-31) -- lanes 28-30
+// get what the rotation gave them anyway, lane 31 gets lane 32's value
+SODA_DEV int soda_swz_up64d(int v) {
+  const int r = __builtin_amdgcn_ds_swizzle(v, SODA_SWZ_ROT_UP);
+  return __builtin_amdgcn_update_dpp(r, v, 0x130, 0x2, 0x8, false);
+}
+template <class T> SODA_DEV T soda_lane_up64d(T v) {
+  static_assert(sizeof(T) == 4, "mix64d: 4-byte cells");
+  return __builtin_bit_cast(T, soda_swz_up64d(__builtin_bit_cast(int, v)));
+}
 template <class T> SODA_DEV T soda_lane_dn32(T v) { return soda_swz<T>::dn32(v); }
 template <class T> SODA_DEV T soda_lane_up32(T v) { return soda_swz<T>::up32(v); }
 template <class T> SODA_DEV T soda_lane_dn64(T v) { return soda_swz<T>::dn64(v); }

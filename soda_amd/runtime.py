@@ -473,7 +473,8 @@ def make_plan(mod: lower.Module,
       d.chunk_fixed = 1 if tune.get('fixed') else 0
       d.vgprs = int((resources or {}).get(k.name, {}).get('vgpr') or 0)
       d.step_ns = float(tune.get('step_ops') or 0.0) * NS_PER_VALU_OP * (
-          MIXH_FACTOR if tune.get('lane_shift') == 'mixh' else 1.0)
+          MIXH_FACTOR if tune.get('lane_shift') in ('mixh', 'mix64',
+                                                    'mix64d') else 1.0)
       d.warm_saved = float(tune.get('warm_saved') or 0.0)
       d.bytes_per_cell = io_bytes
       d.lane_redundancy = float(tune.get('lane_redundancy') or 1.0)

@@ -267,6 +267,7 @@ def test_explicit_chunk_and_wave_shapes(built):
              dict(lane_shift='bperm'), dict(lane_shift='lds'), dict(vec=2),
              dict(lane_shift='swz'), dict(lane_shift='swzh'),
              dict(lane_shift='mixh'), dict(lane_shift='mixh', pipe=3),
+             dict(lane_shift='mix64'), dict(lane_shift='mix64d'),
              dict(vec=1, chunk_rows=33)):
     _check(stencil, (1000, 200), lower.LowerOptions(fuse=(3,), **kw))
   h = core.from_file(soda_path('heat3d.soda'), iterate=2)
