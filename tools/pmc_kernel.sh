@@ -16,13 +16,21 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_V
   tail -1 $out/s$j.log | cut -c1-160
 done
 python3 - <<PY
-import csv, glob, collections, json
-agg=collections.defaultdict(float); n=collections.Counter()
+import csv, glob, collections, json, sys
+agg=collections.defaultdict(float); n=collections.Counter(); names=set()
 for f in glob.glob('$out/s*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if '$pat' in r['Kernel_Name']:
+            names.add(r['Kernel_Name'])
             agg[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 res = {k: round(v / max(1, n[k]), 1) for k, v in sorted(agg.items())}
+# (round 4 summarised a run of ANOTHER variant of the kernel under the benched
+# one's label: the names the counters were taken on are part of the record, and
+# exactly one kernel may match)
+res['kernels'] = sorted(names)
+res['launches_averaged'] = max(n.values()) if n else 0
 print(json.dumps(res))
 json.dump(res, open('$out/summary.json', 'w'), indent=1)
+if len(names) != 1:
+    sys.exit('pmc_kernel.sh: "$pat" matched %d kernels: %s' % (len(names), sorted(names)))
 PY
