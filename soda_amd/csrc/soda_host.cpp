@@ -875,7 +875,9 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
   // kernels then do <= 1.5x the work), at least four bands.  A band is a whole
   // number of staged chunks, two or more.
   const char* bands_env = getenv("SODA_HIP_HOST_BANDS");
-  if (plan.has_reach && !(bands_env && !strcmp(bands_env, "0"))) {
+  // (not in 1-D: a band would start at an arbitrary cell, and the kernels are
+  // built for rows that start on 16-byte boundaries and are whole vectors long)
+  if (plan.has_reach && c.dim >= 2 && !(bands_env && !strcmp(bands_env, "0"))) {
     const int64_t g_lo = (int64_t)iterate * plan.reach_lo;
     const int64_t g_hi = (int64_t)iterate * plan.reach_hi;
     int64_t per_band = (2 * (g_lo + g_hi) + c.chunk_rows - 1) / c.chunk_rows;

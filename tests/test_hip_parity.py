@@ -522,16 +522,28 @@ def test_host_entry_in_bands(built, monkeypatch, kb):
       ('denoise2d.soda', (256, 600), {}, ()),
       ('jacobi2d.soda', (256, 900), dict(iterate=5, border='preserve'), (4,)),
       ('sobel2d.soda', (512, 333), {}, ()),
+      ('coupled2d.soda', (256, 500), dict(iterate=4), (2,)),   # 2 in, 2 out
+      ('conv2d.soda', (256, 420), {}, ()),                     # a param array
+      ('smooth1d', (40000,), {}, ()),                          # 1-D: no bands
   ]
   rng = np.random.default_rng(11)
   for name, extent, kw, fuse in cases:
-    st = core.from_file(soda_path(name), **kw)
+    if name == 'smooth1d':
+      st = core.from_text(
+          'kernel: smooth1d\nburst width: 64\nunroll factor: 2\niterate: 3\n'
+          'input float: a\n'
+          'output float: b(0) = (a(-1) + a(0) * 2.0f + a(1)) * 0.25f')
+    else:
+      st = core.from_file(soda_path(name), **kw)
     shape = extent[::-1]
     ins = {}
     for n, t in zip(st.input_names, st.input_types):
       dt = np.dtype(t.np_name)
       ins[n] = (rng.random(shape).astype(dt) if dt.kind == 'f'
                 else rng.integers(0, 2000, shape).astype(dt))
+    for pstmt in st.param_stmts:           # param arrays: C order, as written
+      ins[pstmt.name] = rng.random(pstmt.size or (1,)).astype(
+          np.dtype(pstmt.haoda_type.np_name))
     want = c_oracle.COracle(st).run(ins)
     runs = {}
     for bands in ('1', '0'):
@@ -539,16 +551,18 @@ def test_host_entry_in_bands(built, monkeypatch, kb):
       with runtime.Program(st, lower.LowerOptions(fuse=fuse),
                            extent=extent) as prog:
         # strided caller arrays: rows with a tail
-        big_in = {n: np.zeros(shape[:-1] + (shape[-1] + 24,), a.dtype)
-                  for n, a in ins.items()}
-        for n, a in ins.items():
-          big_in[n][..., 8:8 + shape[-1]] = a
+        big_in = {n: np.zeros(shape[:-1] + (shape[-1] + 24,), ins[n].dtype)
+                  for n in st.input_names}
+        for n in st.input_names:
+          big_in[n][..., 8:8 + shape[-1]] = ins[n]
         outs_big = {n: np.full(shape[:-1] + (shape[-1] + 10,), 77,
                                np.dtype(t.np_name))
                     for n, t in zip(st.output_names, st.output_types)}
         outs = {n: a[..., 3:3 + shape[-1]] for n, a in outs_big.items()}
-        prog.run({n: a[..., 8:8 + shape[-1]] for n, a in big_in.items()},
-                 outputs=outs)
+        given = {n: a[..., 8:8 + shape[-1]] for n, a in big_in.items()}
+        for pstmt in st.param_stmts:
+          given[pstmt.name] = ins[pstmt.name]
+        prog.run(given, outputs=outs)
         runs[bands] = {n: a.copy() for n, a in outs_big.items()}
     for o in st.output_names:
       assert np.array_equal(runs['1'][o].view(np.uint8),

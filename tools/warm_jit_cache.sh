@@ -1,0 +1,31 @@
+#!/bin/bash
+# The JIT cache (soda_amd/_jit_cache, content-addressed: compiler version +
+# options + kernel text -> code object; git-ignored, travels to the GPU box
+# with the tree like libsoda_hip.so) warmed with everything the GPU test suite
+# compiles.  hiprtc takes 1-3 s per module and the suite builds ~1800 of them:
+# 516 s cold, 135 s warm on one MI355X box (profiles/r05_suite_cold.log,
+# r05_suite_warm.log) -- the driver's GPU run has a time limit.  Stale entries
+# are harmless (never looked up); any edit to soda_rt.h or a generator changes
+# the keys of what it touches, those modules are simply compiled again.
+#
+#   on the GPU box (gpurun):  tools/warm_jit_cache.sh collect
+#   here, afterwards:         tools/warm_jit_cache.sh install
+set -o pipefail
+cd "$(dirname "$0")/.."
+case "$1" in
+  collect)
+    export SODA_HIP_CACHE=$PWD/gpurun_out/jit_cache
+    rm -rf "$SODA_HIP_CACHE"; mkdir -p "$SODA_HIP_CACHE"
+    (time python -m pytest tests -m gpu -q) > gpurun_out/jit_cache_suite.log 2>&1
+    tail -4 gpurun_out/jit_cache_suite.log
+    du -sh "$SODA_HIP_CACHE"; ls "$SODA_HIP_CACHE" | wc -l
+    ;;
+  install)
+    [ -d gpurun_out/jit_cache ] || { echo "run 'collect' through gpurun first"; exit 1; }
+    rm -rf soda_amd/_jit_cache; mkdir -p soda_amd/_jit_cache
+    cp gpurun_out/jit_cache/* soda_amd/_jit_cache/
+    python -c "import __graft_entry__ as g; g.build()"     # + the pre-JIT list
+    du -sh soda_amd/_jit_cache; ls soda_amd/_jit_cache | wc -l
+    ;;
+  *) echo "usage: $0 collect|install"; exit 2;;
+esac
