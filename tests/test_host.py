@@ -278,3 +278,38 @@ def test_wire_kernels_under_independent_hosts(built, tmp_path, main, soda):
                          timeout=300)
     assert run.returncode == 0 and run.stdout.startswith('OK'), (
         chunk_kb, run.stdout + run.stderr)
+
+
+def test_pack_and_unpack_from_several_caller_threads(built):
+  """The worker pool serves one job at a time; callers from several threads
+  take turns (CopyPool::run's `turn_` mutex).  Four Python threads pack big
+  arrays at once (ctypes drops the GIL inside the call): every result right,
+  no deadlock.  tools/sanitize.sh runs this under TSan."""
+  import threading
+  import numpy as np
+  from soda_amd import runtime
+  lib = runtime.library()
+  rng = np.random.default_rng(3)
+  extent = (1500, 1100)
+  arrays = [rng.integers(0, 250, extent[::-1]).astype(np.float32)
+            for _ in range(4)]
+  stages = [np.zeros_like(a) for a in arrays]
+  errors = []
+
+  def work(i):
+    try:
+      for _ in range(5):
+        stages[i][:] = 0
+        _copy_box(lib, arrays[i], stages[i], extent, (0, 0), extent, True, 0, 0)
+        if not np.array_equal(stages[i], arrays[i]):
+          errors.append(i)
+    except Exception as e:     # noqa: BLE001
+      errors.append(repr(e))
+
+  threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  assert not any(t.is_alive() for t in threads), 'a caller never returned'
+  assert not errors, errors

@@ -42,7 +42,7 @@ fail=0
       tests/test_stream.py "tests/test_dist.py::test_exchange_interval_by_the_librarys_cost_choice"
   run "libsoda_hip, TSan: the worker pool of the host-array entry (pack / unpack on 8 threads)" \
       $tsan $lib/libsoda_hip_tsan.so \
-      python -m pytest -q -m "not gpu" -p no:cacheprovider tests/test_host.py -k pack_and_unpack
+      python -m pytest -q -m "not gpu" -p no:cacheprovider tests/test_host.py -k "pack_and_unpack"
   run "generated oracle nests, ASan + UBSan: corpus, golden vectors, fuzz seeds, independent nests" \
       $asan $lib/libsoda_hip_asan.so SODA_ORACLE_SANITIZE=1 SODA_ORACLE_BUILD=/tmp/soda_oracle_asan_$$ \
       python -m pytest -q -m "not gpu" -p no:cacheprovider \
