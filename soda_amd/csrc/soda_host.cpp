@@ -413,7 +413,9 @@ int run_whole(HostCall& c) {
 // copies out -- so that the link is busy in both directions while band i
 // computes.  One host thread drives all of it; whatever it finds to do next,
 // in this order: deliver a fetched chunk, fetch one, launch a band whose
-// input has been sent, send the next input rows, else wait for a fetch.
+// input has been sent, send the next input rows if their slot is free, else
+// look again in 20 us (it never blocks on one of the rings while the other has
+// work for it: blocking sends made C2 10.3 instead of 9.0 ms).
 int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
   soda_hip_program* p = c.p;
   const soda_hip_plan_t& plan = p->plan;
