@@ -29,9 +29,96 @@
 #include <mutex>
 #include <thread>
 
+#include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 
 namespace soda_detail {
+
+// ---- the GPU's NUMA node ------------------------------------------------------
+// The pool's hosts have two sockets with four GPUs each.  Measured
+// (tools/experiments/r05_numa_try.py, the headline step through host arrays):
+// everything on the GPU's node 8.8-9.0 ms, everything on the other node
+// 11.4-11.8 ms, left to the scheduler 8.3-13 ms from run to run.  What the
+// library controls: where its pinned staging slots live (the DMA then stays
+// on the GPU's socket) and where its worker threads run.  The node comes from
+// sysfs (no libnuma in the image); SODA_HIP_HOST_NUMA=0 switches it off; any
+// failure to find out leaves everything unbound.
+struct NumaCpus {
+  bool known = false;
+  cpu_set_t cpus;
+};
+
+const NumaCpus& cpus_near_device(int device) {
+  static std::mutex mu;
+  static std::map<int, NumaCpus> memo;
+  std::lock_guard<std::mutex> hold(mu);
+  auto it = memo.find(device);
+  if (it != memo.end()) return it->second;
+  NumaCpus& out = memo[device];
+  CPU_ZERO(&out.cpus);
+  const char* env = getenv("SODA_HIP_HOST_NUMA");
+  if (env && !strcmp(env, "0")) return out;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return out;
+  }
+  for (char* c = bus; *c; ++c)
+    if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+  int node = -1;
+  if (FILE* f = fopen(path, "r")) {
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+  }
+  if (node < 0) return out;
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return out;
+  char list[4096] = {0};
+  const bool got = fgets(list, sizeof list, f) != nullptr;
+  fclose(f);
+  if (!got) return out;
+  // "0-63,128-191": only CPUs this process may run on anyway
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+  int count = 0;
+  for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int n = sscanf(tok, "%d-%d", &a, &b);
+    if (n < 1) continue;
+    if (n == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &allowed)) {
+        CPU_SET(c, &out.cpus);
+        ++count;
+      }
+  }
+  out.known = count > 0;
+  return out;
+}
+
+// the calling thread on the GPU's node for as long as the object lives: what
+// it allocates (and the driver pins) in between lands in that node's memory
+class RunNear {
+ public:
+  explicit RunNear(int device) {
+    const NumaCpus& near = cpus_near_device(device);
+    if (!near.known) return;
+    if (sched_getaffinity(0, sizeof before_, &before_) != 0) return;
+    moved_ = sched_setaffinity(0, sizeof near.cpus, &near.cpus) == 0;
+  }
+  ~RunNear() {
+    if (moved_) (void)sched_setaffinity(0, sizeof before_, &before_);
+  }
+
+ private:
+  cpu_set_t before_;
+  bool moved_ = false;
+};
 
 // ---- worker threads -----------------------------------------------------------
 // One process-wide pool, made on first use, never destroyed (its threads sleep
@@ -46,6 +133,20 @@ class CopyPool {
     std::lock_guard<std::mutex> hold(make);
     if (!pool || pool->pid_ != getpid()) pool = new CopyPool;   // (leaked)
     return *pool;
+  }
+
+  // the workers onto the CPUs of the node of the GPU the FIRST host-array run
+  // of the process talks to (a process that drives GPUs on both sockets keeps
+  // that choice: its other GPUs' copies cross the socket link as they would
+  // unbound half of the time)
+  void run_near(int device) {
+    std::lock_guard<std::mutex> hold(m_);
+    if (bound_) return;
+    bound_ = true;
+    const NumaCpus& near = cpus_near_device(device);
+    if (!near.known) return;
+    for (pthread_t t : threads_)
+      (void)pthread_setaffinity_np(t, sizeof near.cpus, &near.cpus);
   }
 
   int threads() const { return (int)workers_ + 1; }
@@ -81,8 +182,11 @@ class CopyPool {
     if (have > 0 && want > have) want = have;
     if (want < 1) want = 1;
     workers_ = (size_t)want - 1;
-    for (size_t i = 0; i < workers_; ++i)
-      std::thread([this] { loop(); }).detach();
+    for (size_t i = 0; i < workers_; ++i) {
+      std::thread t([this] { loop(); });
+      threads_.push_back(t.native_handle());
+      t.detach();
+    }
   }
 
   void work() {
@@ -109,6 +213,8 @@ class CopyPool {
 
   const pid_t pid_;
   size_t workers_ = 0;
+  std::vector<pthread_t> threads_;
+  bool bound_ = false;
   std::mutex turn_, m_;
   std::condition_variable wake_, done_;
   const std::function<void(size_t)>* job_ = nullptr;
@@ -236,6 +342,17 @@ void HostRing::release() {
   slot_bytes = 0;
   slots = 0;
   for (bool& b : busy) b = false;
+}
+
+// A program's ring, big enough, its memory on the GPU's NUMA node (the thread
+// that allocates runs there while it does) and the worker threads with it.
+int ensure_ring(soda_hip_program* p, HostRing* ring, size_t slot_bytes,
+                int slots) {
+  CopyPool::get().run_near(p->device);
+  if (ring->base && ring->slot_bytes >= slot_bytes && ring->slots >= slots)
+    return SODA_HIP_OK;
+  RunNear near(p->device);
+  return ring->ensure(slot_bytes, slots);
 }
 
 namespace {
@@ -606,7 +723,7 @@ int ring_send(soda_hip_program* p, void* dev, const void* host, size_t bytes,
   const size_t target = chunk_target_bytes();
   const size_t chunk = bytes < target ? bytes : target;
   const int slots = chunk < bytes ? HostRing::kMaxSlots : 1;
-  if (int rc = p->ring_in.ensure(chunk, slots)) return rc;
+  if (int rc = ensure_ring(p, &p->ring_in, chunk, slots)) return rc;
   const int32_t one = 1;
   int turn = 0;
   for (size_t off = 0; off < bytes; off += chunk, ++turn) {
@@ -633,7 +750,7 @@ int ring_fetch(soda_hip_program* p, void* host, const void* dev, size_t bytes,
   const size_t target = chunk_target_bytes();
   const size_t chunk = bytes < target ? bytes : target;
   const int slots = chunk < bytes ? HostRing::kMaxSlots : 1;
-  if (int rc = p->ring_out.ensure(chunk, slots)) return rc;
+  if (int rc = ensure_ring(p, &p->ring_out, chunk, slots)) return rc;
   const int32_t one = 1;
   const int64_t nchunk = (int64_t)((bytes + chunk - 1) / chunk);
   for (int64_t c = 0; c < nchunk + slots - 1; ++c) {
@@ -685,7 +802,8 @@ int send_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
   for (int d = 0; d < ax; ++d) plane *= extent[d];
   const int64_t step = rows_per_chunk(plane * elem, b - a);
   const int slots = step < b - a ? HostRing::kMaxSlots : 1;
-  if (int rc = p->ring_in.ensure((size_t)step * plane * elem, slots)) return rc;
+  if (int rc = ensure_ring(p, &p->ring_in, (size_t)step * plane * elem, slots))
+    return rc;
   int turn = 0;
   for (int64_t r = a; r < b; r += step, ++turn) {
     const int64_t e = r + step < b ? r + step : b;
@@ -729,7 +847,8 @@ int fetch_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
   for (int d = 0; d < ax; ++d) plane *= extent[d];
   const int64_t step = rows_per_chunk(plane * elem, b - a);
   const int slots = step < b - a ? HostRing::kMaxSlots : 1;
-  if (int rc = p->ring_out.ensure((size_t)step * plane * elem, slots)) return rc;
+  if (int rc = ensure_ring(p, &p->ring_out, (size_t)step * plane * elem, slots))
+    return rc;
   const int64_t nchunk = (b - a + step - 1) / step;
   for (int64_t c = 0; c < nchunk + slots - 1; ++c) {
     if (c < nchunk) {
@@ -853,8 +972,8 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
   if (c.chunk_rows > c.rows) c.chunk_rows = c.rows;
   c.slots = c.chunk_rows < c.rows ? HostRing::kMaxSlots : 1;
   const size_t slot_bytes = (size_t)c.chunk_rows * c.plane * max_elem;
-  if (int rc = p->ring_in.ensure(slot_bytes, c.slots)) return rc;
-  if (int rc = p->ring_out.ensure(slot_bytes, c.slots)) return rc;
+  if (int rc = ensure_ring(p, &p->ring_in, slot_bytes, c.slots)) return rc;
+  if (int rc = ensure_ring(p, &p->ring_out, slot_bytes, c.slots)) return rc;
   c.in_ptrs.resize(plan.num_inputs);
   for (int i = 0; i < plan.num_inputs; ++i) {
     if (int rc = ensure(p->host_in[i], (size_t)c.cells * plan.elem_size[i]))
