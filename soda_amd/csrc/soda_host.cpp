@@ -712,6 +712,92 @@ int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
   return SODA_HIP_OK;
 }
 
+// Rows per band by a timeline estimate, 0 = do not band, -1 = the plan has no
+// time model.  Three resources in sequence per band -- the link in (rows
+// arrive in order), the kernels (a band waits for its last ghost row and for
+// the band before it), the link out -- at the rates measured on the pool's
+// hosts (profiles/r05_hostcopy.jsonl: 57 GB/s one way alone, 48 each with both
+// busy; the host threads pack and deliver ~60 GB/s in total), kernel time from
+// the library's own pass times (calibrated if this extent was, else the
+// model), inflated 15 % for the thinner grids of bands plus 20 us per launch.
+// Bands must win by 10 % to be chosen.
+int64_t choose_bands(HostCall& c, int64_t g_lo, int64_t g_hi) {
+  soda_hip_program* p = c.p;
+  const soda_hip_plan_t& plan = p->plan;
+  int32_t ext[SODA_HIP_MAX_DIM];
+  ExtentKey key;
+  for (int d = 0; d < SODA_HIP_MAX_DIM; ++d) {
+    ext[d] = d < c.dim ? c.extent[d] : 1;
+    key[d] = ext[d];
+  }
+  const ExtentPlan* ep = nullptr;
+  if (extent_plan(plan, &p->extents, ext, &ep)) return -1;
+  auto it = p->measured.find(key);
+  const std::vector<double>& pass_ns =
+      it != p->measured.end() ? it->second : ep->model_ns;
+  for (int i = 0; i < plan.num_passes; ++i)
+    if (!(pass_ns[i] > 0)) return -1;
+  int32_t count[SODA_HIP_MAX_PASSES], total = 0;
+  if (schedule(plan, pass_ns, c.iterate, count, &total)) return -1;
+  double compute_ns = 0;
+  for (int i = 0; i < plan.num_passes; ++i) compute_ns += count[i] * pass_ns[i];
+  double in_row = 0, out_row = 0;        // bytes per index of the last dimension
+  for (int i = 0; i < plan.num_inputs; ++i)
+    in_row += (double)c.plane * plan.elem_size[i];
+  int64_t out_lo = c.rows, out_hi = 0;   // rows some valid box holds
+  for (int o = 0; o < plan.num_outputs; ++o) {
+    if (c.empty(o)) continue;
+    out_row += (double)c.plane * plan.elem_size[plan.num_inputs + o];
+    if (c.lo(o)[c.ax] < out_lo) out_lo = c.lo(o)[c.ax];
+    if (c.hi(o)[c.ax] > out_hi) out_hi = c.hi(o)[c.ax];
+  }
+  if (out_hi <= out_lo) return 0;
+  const double kAlone = 57.0, kBoth = 48.0, kHost = 60.0;   // bytes per ns
+  const double whole = c.rows * in_row / kAlone + compute_ns +
+                       (out_hi - out_lo) * out_row / kAlone;
+  const double host_floor =
+      (c.rows * in_row + (out_hi - out_lo) * out_row) / kHost;
+  double best = whole * 0.9;
+  int64_t best_rows = 0;
+  for (int64_t per_band = 1; per_band * c.chunk_rows < c.rows; ++per_band) {
+    const int64_t band = per_band * c.chunk_rows;
+    const int64_t nb = (c.rows + band - 1) / band;
+    if (nb < 2) break;
+    if (nb > 64) continue;               // (thinner bands never won)
+    double run_end = 0, out_end = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      const int64_t r0 = b * band, r1 = r0 + band < c.rows ? r0 + band : c.rows;
+      const int64_t gl = g_lo < r0 ? g_lo : r0;
+      const int64_t gh = g_hi < c.rows - r1 ? g_hi : c.rows - r1;
+      // (whole chunks arrive: the band's last row rounded up to a chunk)
+      int64_t need = (r1 + gh + c.chunk_rows - 1) / c.chunk_rows * c.chunk_rows;
+      if (need > c.rows) need = c.rows;
+      const double arrived = need * in_row / kBoth;
+      const double run = compute_ns * (double)(r1 - r0 + gl + gh) / c.rows * 1.15 +
+                         20000.0 * total;
+      const double start = arrived > run_end ? arrived : run_end;
+      run_end = start + run;
+      const int64_t a = r0 > out_lo ? r0 : out_lo, e = r1 < out_hi ? r1 : out_hi;
+      if (e > a) {
+        const double s0 = run_end > out_end ? run_end : out_end;
+        out_end = s0 + (e - a) * out_row / kBoth;
+      }
+    }
+    double t = out_end > run_end ? out_end : run_end;
+    if (t < host_floor) t = host_floor;
+    if (t < best) {
+      best = t;
+      best_rows = band;
+    }
+  }
+  if (getenv("SODA_HIP_HOST_TRACE"))
+    fprintf(stderr, "soda_hip_run_host_box: estimate whole %.2f ms (kernels "
+            "%.2f), best bands of %lld rows %.2f ms\n", whole / 1e6,
+            compute_ns / 1e6, (long long)best_rows,
+            best_rows ? best / 1e6 : 0.0);
+  return best_rows;
+}
+
 }  // namespace
 
 // Contiguous host bytes -> device through the program's input ring: chunk i + 1
@@ -992,19 +1078,31 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
                            hipMemcpyHostToDevice, p->hstream[0]));
     c.in_ptrs.push_back(p->host_prm[k].ptr);
   }
-  // Bands pay where copying dominates: ghost rows at most half a band (the
-  // kernels then do <= 1.5x the work), at least four bands.  A band is a whole
-  // number of staged chunks, two or more.
+  // Bands or not, and how thick.  SODA_HIP_HOST_BANDS=0: never; =1: by the
+  // rule of the first version (ghost rows at most half a band, at least four
+  // bands of two or more staged chunks -- what the tests force onto small
+  // grids); unset: by a timeline estimate of both ways (choose_bands), which
+  // also bands runs the rule leaves whole -- heat3d 512^3 x 50: two bands of
+  // 256 + 100 ghost planes do 1.4x the arithmetic and still finish earlier,
+  // because the first band computes while the second half of the input is on
+  // the link and its result leaves while the second band computes.
   const char* bands_env = getenv("SODA_HIP_HOST_BANDS");
+  const bool never = bands_env && !strcmp(bands_env, "0");
+  const bool by_rule = bands_env && !strcmp(bands_env, "1");
   // (not in 1-D: a band would start at an arbitrary cell, and the kernels are
   // built for rows that start on 16-byte boundaries and are whole vectors long)
-  if (plan.has_reach && c.dim >= 2 && !(bands_env && !strcmp(bands_env, "0"))) {
+  if (plan.has_reach && c.dim >= 2 && !never) {
     const int64_t g_lo = (int64_t)iterate * plan.reach_lo;
     const int64_t g_hi = (int64_t)iterate * plan.reach_hi;
-    int64_t per_band = (2 * (g_lo + g_hi) + c.chunk_rows - 1) / c.chunk_rows;
-    if (per_band < 2) per_band = 2;
-    const int64_t band_rows = per_band * c.chunk_rows;
-    if (band_rows * 4 <= c.rows + band_rows - 1)     // ceil(rows / band) >= 4
+    int64_t band_rows = 0;
+    if (!by_rule) band_rows = choose_bands(c, g_lo, g_hi);
+    if (by_rule || band_rows < 0) {        // (< 0: no time model for this plan)
+      int64_t per_band = (2 * (g_lo + g_hi) + c.chunk_rows - 1) / c.chunk_rows;
+      if (per_band < 2) per_band = 2;
+      band_rows = per_band * c.chunk_rows;
+      if (band_rows * 4 > c.rows + band_rows - 1) band_rows = 0;   // < 4 bands
+    }
+    if (band_rows > 0 && band_rows < c.rows)
       return run_banded(c, band_rows, g_lo, g_hi);
   }
   return run_whole(c);
