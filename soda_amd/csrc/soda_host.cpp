@@ -717,7 +717,7 @@ int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
 // arrive in order), the kernels (a band waits for its last ghost row and for
 // the band before it), the link out -- at the rates measured on the pool's
 // hosts (profiles/r05_hostcopy.jsonl: 57 GB/s one way alone, 48 each with both
-// busy; the host threads pack and deliver ~60 GB/s in total), kernel time from
+// busy; the host threads pack and deliver 60-85 GB/s in total), kernel time from
 // the library's own pass times (calibrated if this extent was, else the
 // model), inflated 15 % for the thinner grids of bands plus 20 us per launch.
 // Bands must win by 10 % to be chosen.
@@ -752,7 +752,7 @@ int64_t choose_bands(HostCall& c, int64_t g_lo, int64_t g_hi) {
     if (c.hi(o)[c.ax] > out_hi) out_hi = c.hi(o)[c.ax];
   }
   if (out_hi <= out_lo) return 0;
-  const double kAlone = 57.0, kBoth = 48.0, kHost = 60.0;   // bytes per ns
+  const double kAlone = 57.0, kBoth = 48.0, kHost = 85.0;   // bytes per ns
   const double whole = c.rows * in_row / kAlone + compute_ns +
                        (out_hi - out_lo) * out_row / kAlone;
   const double host_floor =

@@ -546,8 +546,11 @@ def test_host_entry_in_bands(built, monkeypatch, kb):
           np.dtype(pstmt.haoda_type.np_name))
     want = c_oracle.COracle(st).run(ins)
     runs = {}
-    for bands in ('1', '0'):
-      monkeypatch.setenv('SODA_HIP_HOST_BANDS', bands)
+    for bands in ('1', '0', 'estimate'):
+      if bands == 'estimate':      # the library's own choice (choose_bands)
+        monkeypatch.delenv('SODA_HIP_HOST_BANDS')
+      else:
+        monkeypatch.setenv('SODA_HIP_HOST_BANDS', bands)
       with runtime.Program(st, lower.LowerOptions(fuse=fuse),
                            extent=extent) as prog:
         # strided caller arrays: rows with a tail
@@ -566,6 +569,8 @@ def test_host_entry_in_bands(built, monkeypatch, kb):
         runs[bands] = {n: a.copy() for n, a in outs_big.items()}
     for o in st.output_names:
       assert np.array_equal(runs['1'][o].view(np.uint8),
+                            runs['0'][o].view(np.uint8)), (name, o)
+      assert np.array_equal(runs['estimate'][o].view(np.uint8),
                             runs['0'][o].view(np.uint8)), (name, o)
       got = runs['1'][o][..., 3:3 + shape[-1]]
       if st.preserve_border:

@@ -58,8 +58,11 @@ def main():
       continue
     os.environ['SODA_HIP_HOST_CHUNK_KB'] = str(int(rng.choice(
         [16, 64, 256, 1024, 4096, 16384])))
-    bands = str(int(rng.integers(0, 4) > 0))
-    os.environ['SODA_HIP_HOST_BANDS'] = bands
+    # never / by the rule / by the library's own estimate
+    bands = ['0', '1', '1', ''][int(rng.integers(0, 4))]
+    os.environ.pop('SODA_HIP_HOST_BANDS', None)
+    if bands:
+      os.environ['SODA_HIP_HOST_BANDS'] = bands
     shape = extent[::-1]
     pad_in, pad_out = int(rng.integers(0, 3)) * 8, int(rng.integers(0, 3)) * 4
     ins, big = {}, {}
