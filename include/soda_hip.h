@@ -381,7 +381,15 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
  * (SODA_HIP_HOST_CHUNK_MB), packed / unpacked by a process-wide pool of worker
  * threads (SODA_HIP_HOST_THREADS, default 8 -- the reference's pack and unpack
  * loops carry `#pragma omp parallel for`, frt/host.py:193,357) while the DMA
- * engine moves the neighbouring chunk.  The pack / unpack step alone, exported
+ * engine moves the neighbouring chunk.  With the program's per-iteration reach
+ * in the plan (has_reach) a 2-D / 3-D run is cut into bands along the last
+ * dimension -- window runs with iterate x reach ghost rows -- where a timeline
+ * estimate of copy-in / kernels / copy-out says the overlap wins
+ * (SODA_HIP_HOST_BANDS=0: never, =1: by a fixed rule; SODA_HIP_HOST_TRACE=1
+ * prints the estimates and where the host thread's time went).  Slots and
+ * worker threads live on the GPU's NUMA node (SODA_HIP_HOST_NUMA=0: wherever
+ * the scheduler puts them).  Results are the same bits either way.
+ * The pack / unpack step alone, exported
  * for callers that stage their own transfers and for tests without a GPU:
  * copies box [lo, hi) between a strided host array (strides in elements) and
  * a dense array that starts at index `row0` of the last dimension (0: holds
