@@ -12,14 +12,58 @@ FLOAT_TYPES = ['float', 'double']
 INT_TYPES = ['uint8', 'int16', 'uint16', 'int32']
 
 
-def budget() -> float:
-  """`--fuzz-budget` / $SODA_FUZZ_BUDGET: how much of the GPU run's time the
-  random-program tests may take, relative to the default sets."""
+_BUDGET = None
+
+
+def _cache_is_warm() -> bool:
+  """Was the JIT cache (soda_amd/_jit_cache) filled by a run of the FULL seed
+  sets (tools/warm_jit_cache.sh)?  Asked precisely: the code object of one
+  program only the full sets contain -- the last valid plain seed below 100 --
+  lowered as test_gpu_matches_oracle lowers it, is looked up by its content
+  key.  hiprtc takes 1-3 s per module; with the cache the full sets cost the
+  GPU run ~1 minute more, without it ~5."""
   import os
   try:
-    return max(0.0, float(os.environ.get('SODA_FUZZ_BUDGET', '1') or 1))
-  except ValueError:
-    return 1.0
+    from soda_amd import core, runtime, util
+    from soda_amd.codegen.hip import lower
+    for seed in range(99, 49, -1):
+      text, dim, _ = program(seed)
+      try:
+        stencil = core.from_text(text)
+      except util.SodaError:
+        continue
+      extent = extent_for(seed, dim)
+      lo, hi = stencil.valid_box(extent)
+      if not all(h > l for l, h in zip(lo, hi)):
+        continue
+      opts = runtime.resolve_options(
+          stencil, lower.LowerOptions(strategy='direct', fuse=(2,)), extent)
+      mod = lower.lower(stencil, opts)
+      key = runtime.source_key(mod.source)
+      name = ('%s.hip' % stencil.app_name).replace('.', '_')
+      return os.path.exists(os.path.join(runtime.CACHE_DIR,
+                                         '%s_%s.hsaco' % (name, key)))
+  except Exception:      # noqa: BLE001 -- no library, no cache: the default sets
+    return False
+  return False
+
+
+def budget() -> float:
+  """`--fuzz-budget` / $SODA_FUZZ_BUDGET: how much of the GPU run's time the
+  random-program tests may take, relative to the sets sized for a COLD run
+  (1).  Not given: 2 -- the full sets of rounds 2-3 -- when the JIT cache holds
+  their code objects already, else 1."""
+  global _BUDGET
+  import os
+  given = os.environ.get('SODA_FUZZ_BUDGET')
+  if given:
+    try:
+      return max(0.0, float(given))
+    except ValueError:
+      return 1.0
+  if _BUDGET is None:
+    _BUDGET = 2.0 if _cache_is_warm() else 1.0
+  return _BUDGET
 
 
 def budget_seeds(default: int, full: int, pinned=()):

@@ -12,12 +12,14 @@ from soda_amd import core, util
 
 CPU_SEEDS = range(0, 40)
 # The GPU seed sets scale with `--fuzz-budget B` (tests/conftest.py; env
-# SODA_FUZZ_BUDGET): B = 1, the default, is sized for the driver's GPU run
-# (~10 minutes for the whole suite; tests/test_fuzz_nest.py runs 3 x 30 more
-# programs against nests that do not share the product's front-end); B = 2
-# restores the full sets of rounds 2-3 (100 / 100 / 45 / 60 seeds) for a
-# nightly-style run; B < 1 shortens them.  Seeds that once found a defect are
-# pinned in every set, whatever the budget.
+# SODA_FUZZ_BUDGET): B = 1 is sized for a GPU run that has to COMPILE every
+# module (~9 minutes for the whole suite, of which three quarters hiprtc);
+# B = 2 is the full sets of rounds 2-3 (100 / 100 / 45 / 60 seeds).  Not given,
+# B is 2 when the JIT cache already holds the full sets' code objects
+# (tools/warm_jit_cache.sh; tests/fuzz.py _cache_is_warm: the suite then takes
+# ~3 minutes), else 1 -- round 4 had to trim seeds by hand to stay inside the
+# driver's time limit.  Seeds that once found a defect are pinned in every
+# set, whatever the budget.
 GPU_SEEDS = fuzz.budget_seeds(50, 100)
 
 

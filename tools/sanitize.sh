@@ -20,6 +20,9 @@ fail=0
 {
   echo "# tools/sanitize.sh, $(date -u +%FT%TZ), $(gcc --version | head -1)"
   make -C soda_amd/csrc asan tsan 2>&1 | tail -3 || fail=1
+  # the product library up to date BEFORE a sanitizer runtime is preloaded (the
+  # tests' `built` fixture would otherwise run hipcc under it)
+  python -c "import __graft_entry__ as g; g.build_library()" || fail=1
   # (SODA_HIP_NO_TORCH: the library binds to /opt/rocm's HIP runtime instead of
   # PyTorch's copy -- nothing here touches a GPU, and PyTorch under a preloaded
   # sanitizer runtime is slow and noisy)
@@ -30,8 +33,10 @@ fail=0
         ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
         UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
         TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 \
-        "$@" 2>&1 | tail -6
-    local rc=${PIPESTATUS[0]}
+        "$@" > /tmp/soda_sanitize_section.log 2>&1
+    local rc=$?
+    tail -6 /tmp/soda_sanitize_section.log
+    [ $rc -eq 0 ] || cp /tmp/soda_sanitize_section.log "/tmp/soda_sanitize_failed_$(date +%s).log"
     echo "exit code $rc"
     [ $rc -eq 0 ] || fail=1
   }
@@ -39,7 +44,10 @@ fail=0
       $asan $lib/libsoda_hip_asan.so \
       python -m pytest -q -m "not gpu" -p no:cacheprovider \
       tests/test_codegen.py tests/test_group.py tests/test_host.py \
-      tests/test_stream.py "tests/test_dist.py::test_exchange_interval_by_the_librarys_cost_choice"
+      tests/test_stream.py "tests/test_dist.py::test_exchange_interval_by_the_librarys_cost_choice" \
+      --deselect tests/test_group.py::test_geometry_of_a_tall_stream_is_cheap
+  # (deselected: a wall-clock assertion -- plan_geometry of a 2M-row stream in
+  # under 10 ms -- that an instrumented build on a busy box misses now and then)
   run "libsoda_hip, TSan: the worker pool of the host-array entry (pack / unpack on 8 threads)" \
       $tsan $lib/libsoda_hip_tsan.so \
       python -m pytest -q -m "not gpu" -p no:cacheprovider tests/test_host.py -k "pack_and_unpack"

@@ -14,16 +14,22 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 case "$1" in
   collect)
-    export SODA_HIP_CACHE=$PWD/gpurun_out/jit_cache
+    # (the FULL random-program seed sets: tests/fuzz.py then finds them in the
+    # cache and runs them by default; outside gpurun_out while it fills, one
+    # compressed file back -- gpurun merges at most 64 MiB)
+    export SODA_HIP_CACHE=/tmp/soda_jit_cache_$$
     rm -rf "$SODA_HIP_CACHE"; mkdir -p "$SODA_HIP_CACHE"
-    (time python -m pytest tests -m gpu -q) > gpurun_out/jit_cache_suite.log 2>&1
+    (time python -m pytest tests -m gpu -q --fuzz-budget 2) > gpurun_out/jit_cache_suite.log 2>&1
     tail -4 gpurun_out/jit_cache_suite.log
     du -sh "$SODA_HIP_CACHE"; ls "$SODA_HIP_CACHE" | wc -l
+    rm -rf gpurun_out/jit_cache
+    tar -C "$SODA_HIP_CACHE" -czf gpurun_out/jit_cache.tgz . && ls -la gpurun_out/jit_cache.tgz
+    rm -rf "$SODA_HIP_CACHE"
     ;;
   install)
-    [ -d gpurun_out/jit_cache ] || { echo "run 'collect' through gpurun first"; exit 1; }
+    [ -f gpurun_out/jit_cache.tgz ] || { echo "run 'collect' through gpurun first"; exit 1; }
     rm -rf soda_amd/_jit_cache; mkdir -p soda_amd/_jit_cache
-    cp gpurun_out/jit_cache/* soda_amd/_jit_cache/
+    tar -C soda_amd/_jit_cache -xzf gpurun_out/jit_cache.tgz
     python -c "import __graft_entry__ as g; g.build()"     # + the pre-JIT list
     du -sh soda_amd/_jit_cache; ls soda_amd/_jit_cache | wc -l
     ;;
