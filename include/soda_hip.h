@@ -579,7 +579,11 @@ int soda_hip_group_last_stats(soda_hip_group_t* group,
  * run the program on the de-interleaved stream -- as the original n-D program
  * with the marching kernels when the stream is a dense array of rows, else as
  * the linearised 1-D program -- and write the outputs back shifted by their
- * stencil offset (frt/host.py:400-424) and re-interleaved. */
+ * stencil offset (frt/host.py:400-424) and re-interleaved.  A program built
+ * to store its outputs at their wire positions (`sodac --hip-wire-kernel`
+ * does: store index moved by the window point of largest linear offset)
+ * declares shift 0 for them; such an output on ONE bank is written by the
+ * program straight into the caller's bank and has no copy kernel. */
 typedef struct soda_hip_stream_desc {
   int32_t dim;                         /* of the original program */
   int32_t num_inputs;
@@ -594,8 +598,10 @@ typedef struct soda_hip_stream_desc {
                                           width x banks (frt/host.py:120-122) */
   int32_t shift[SODA_HIP_MAX_TENSORS]; /* inputs: produce offset the host delays
                                           the tensor by (frt/host.py:241-246);
-                                          outputs: stencil offset the kernel
-                                          emits a cell late by (:401-408) */
+                                          outputs: what is LEFT of the stencil
+                                          offset the kernel emits a cell late
+                                          by (:401-408) for the copy kernel to
+                                          apply; 0 = the program did it */
   int32_t num_linear;                  /* 1-D programs offered, widest first */
   int32_t linear_vec[4];               /* their cells per thread; the last is 1 */
 } soda_hip_stream_desc_t;
@@ -604,9 +610,9 @@ typedef struct soda_hip_stream soda_hip_stream_t;      /* opaque */
 
 /* `dense`: the original program (NULL: always the linear form); `linear`:
  * num_linear programs of the linearised 1-D form; `unwire[i]` / `wire[o]`: the
- * copy kernels of input i / output o as one-kernel programs (unwire[i] may be
- * NULL for an input with one bank and no shift).  The stream borrows the
- * programs; the caller destroys them after the stream. */
+ * copy kernels of input i / output o as one-kernel programs (unwire[i] /
+ * wire[o] may be NULL for a tensor on one bank with shift 0).  The stream
+ * borrows the programs; the caller destroys them after the stream. */
 int soda_hip_stream_create(const soda_hip_stream_desc_t* desc,
                            soda_hip_program_t* dense,
                            soda_hip_program_t* const* linear,

@@ -124,15 +124,30 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
   L.append('  if (soda_rows_ok && %s) {' % ' && '.join(first_ok))
 
   # ---- all cells interior: shared row buffers --------------------------------
-  rows: Dict[Tuple[str, Tuple[int, ...]], Tuple[str, int]] = {}
-  spans: Dict[Tuple[str, Tuple[int, ...]], List[int]] = {}
+  # A row's taps far apart along dimension 0 (the linearised 1-D form of a
+  # wire stream: every tap of the n-D program lies in ONE row, whole tile rows
+  # apart) are fetched as separate runs -- one buffer over the whole span would
+  # be a tile row or more per thread (512 x 512 tiles: 2 MB of stack, refused
+  # by the compiler).
+  rows: Dict[Tuple, Tuple[str, int]] = {}
+  taps0: Dict[Tuple[str, Tuple[int, ...]], set] = {}
   for ref in ir.get_loads(stage.stmt.expr):
     if ref.name in st.param_names:
       continue
     off = tuple(a - b for a, b in zip(ref.idx, stage.st_idx))
-    key = (ref.name, off[1:])
-    sp = spans.setdefault(key, [off[0], off[0]])
-    sp[0], sp[1] = min(sp[0], off[0]), max(sp[1], off[0])
+    taps0.setdefault((ref.name, off[1:]), set()).add(off[0])
+  gap = max(V, 8)
+  run_of: Dict[Tuple, int] = {}
+  spans: Dict[Tuple, List[int]] = {}
+  for (pname, rest), offs in taps0.items():
+    run, last = 0, None
+    for o in sorted(offs):
+      if last is not None and o - last > gap:
+        run += 1
+      last = o
+      run_of[(pname, rest, o)] = run
+      sp = spans.setdefault((pname, rest, run), [o, o])
+      sp[1] = o
   body: List[str] = []
 
   def mk_load(e: int):
@@ -141,7 +156,7 @@ def _direct_rows_kernel(mod: Module, stage: core.Stage, name: str,
       if prm is not None:
         return prm
       off = tuple(a - b for a, b in zip(ref.idx, stage.st_idx))
-      key = (ref.name, off[1:])
+      key = (ref.name, off[1:], run_of[(ref.name, off[1:], off[0])])
       if key not in rows:
         mn, mx = spans[key]
         var = 'rb%d_%s' % (len(rows), ref.name)

@@ -1398,8 +1398,13 @@ int soda_hip_stream_create(const soda_hip_stream_desc_t* desc,
       return fail(SODA_HIP_ERR_INVALID, "stream_create: missing unwire kernel");
   for (int k = 0; k < desc->num_linear; ++k)
     if (!linear[k]) return fail(SODA_HIP_ERR_INVALID, "stream_create: NULL linear");
-  for (int o = 0; o < desc->num_outputs; ++o)
-    if (!wire[o]) return fail(SODA_HIP_ERR_INVALID, "stream_create: NULL wire");
+  // an output on one bank that the program stores at its wire position (shift
+  // 0) needs no copy kernel: the program writes the caller's bank
+  for (int o = 0; o < desc->num_outputs; ++o) {
+    const int t = desc->num_inputs + o;
+    if (!wire[o] && (desc->banks[t] > 1 || desc->shift[t]))
+      return fail(SODA_HIP_ERR_INVALID, "stream_create: missing wire kernel");
+  }
   soda_hip_stream* s = new (std::nothrow) soda_hip_stream;
   if (!s) return fail(SODA_HIP_ERR_NOMEM, "new stream");
   s->desc = *desc;
@@ -1459,7 +1464,15 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
     bank0 += nb;
   }
   std::vector<void*> dout(d.num_outputs);
-  for (int o = 0; o < d.num_outputs; ++o) {
+  bank0 = 0;
+  for (int o = 0; o < d.num_outputs; bank0 += d.banks[d.num_inputs + o], ++o) {
+    for (int b = 0; b < d.banks[d.num_inputs + o]; ++b)
+      if (!out_banks[bank0 + b])
+        return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL output bank");
+    if (!s->wire[o]) {
+      dout[o] = out_banks[bank0];   // born at its wire position, in place
+      continue;
+    }
     const size_t bytes = (size_t)n * d.elem_size[d.num_inputs + o];
     const void* before = s->dense_out[o].ptr;
     if (int rc = ensure(s->dense_out[o], bytes)) return rc;
@@ -1506,16 +1519,12 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
   }
   // 3. outputs: shifted by the stencil offset, re-interleaved
   bank0 = 0;
-  for (int o = 0; o < d.num_outputs; ++o) {
-    const int nb = d.banks[d.num_inputs + o];
-    for (int b = 0; b < nb; ++b)
-      if (!out_banks[bank0 + b])
-        return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL output bank");
+  for (int o = 0; o < d.num_outputs; bank0 += d.banks[d.num_inputs + o], ++o) {
+    if (!s->wire[o]) continue;
     const void* ins[1] = {dout[o]};
     if (int rc = soda_hip_run_device(s->wire[o], out_banks + bank0, ins, ext1, 1,
                                      hip_stream))
       return rc;
-    bank0 += nb;
   }
   return SODA_HIP_OK;
 }
@@ -1557,7 +1566,12 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
       const int t = d.num_inputs + o;
       const size_t bytes = (size_t)coalesced_data_num * d.elems_per_cycle[t] /
                            d.banks[t] * d.elem_size[t];
+      const void* before = s->host_banks[slot].ptr;
       if (int rc = ensure(s->host_banks[slot], bytes)) return rc;
+      // void positions a program writing in place never touches: the same
+      // bytes for the caller run after run
+      if (s->host_banks[slot].ptr != before)
+        HIP_TRY(hipMemsetAsync(s->host_banks[slot].ptr, 0, bytes, stream));
       dev_out.push_back(s->host_banks[slot].ptr);
       out_bytes.push_back(bytes);
     }

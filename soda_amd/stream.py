@@ -82,6 +82,63 @@ def stencil_offsets(stencil: core.Stencil) -> Dict[str, int]:
   return out
 
 
+def emit_late(stencil: core.Stencil) -> Optional[core.Stencil]:
+  """The program whose outputs are BORN at their wire positions, or None.
+
+  The kernel owes output cell L at stream position L + stencil_offset
+  (frt/host.py:401-408).  serialize() is linear, so storing the cell c further
+  on in n-D -- `out(s + c) = expr` instead of `out(s) = expr`, c the point of
+  the output's one-iteration window with the largest linear offset -- puts it
+  exactly there, in the linear form and on the dense (tile..., rows) view
+  alike, and the shift + copy pass over every output goes away.  A cell the
+  host reads has its whole window inside its tile, c is a point of that window,
+  so its new position is inside the tile too.
+
+  Iterated programs feed every output back as an input: each iteration then
+  moves the field by c, `iterate` x c in all -- which is the stencil offset of
+  the iterated program only while one tensor circulates (the largest linear
+  offset of a Minkowski sum is the sum of the largest offsets); with several
+  the inputs of the next iteration would sit at different displacements, so
+  those keep the copy pass."""
+  st = stencil
+  if st.iterate > 1 and (len(st.input_names) != 1 or len(st.output_names) != 1):
+    return None
+  tile = st.tile_size
+  total = stencil_offsets(st)
+  late: Dict[str, tuple] = {}
+  for s in st.output_stmts:
+    pts = st.stencil_window_points(s.name, iterate=1)
+    c = max(pts, key=lambda p: util.serialize(p, tile))
+    if util.serialize(c, tile) * st.iterate != total[s.name]:
+      return None
+    late[s.name] = tuple(c)
+
+  def moved(node):
+    # a later statement that reads an output reads it where it now lives
+    if isinstance(node, ir.Ref) and node.name in late:
+      return ir.Ref(node.name,
+                    tuple(i + c for i, c in zip(node.idx, late[node.name])),
+                    node.lat, node.haoda_type)
+    return node
+
+  def conv(stmt, cls):
+    idx = stmt.ref.idx
+    if stmt.ref.name in late:
+      idx = tuple(i + c for i, c in zip(idx, late[stmt.ref.name]))
+    return cls(stmt.haoda_type, ir.Ref(stmt.ref.name, idx),
+               stmt.expr.transform(moved),
+               [l.transform(moved) for l in stmt.let], getattr(stmt, 'dram', ()))
+
+  return core.Stencil(
+      burst_width=st.burst_width, border=st.border, iterate=st.iterate,
+      cluster=st.cluster, app_name=st.app_name, input_stmts=st.input_stmts,
+      param_stmts=[],
+      local_stmts=[conv(s, grammar.LocalStmt) for s in st.local_stmts],
+      output_stmts=[conv(s, grammar.OutputStmt) for s in st.output_stmts],
+      dim=st.dim, tile_size=st.tile_size, unroll_factor=st.unroll_factor,
+      replication_factor=st.replication_factor)
+
+
 class WireLayout:
   """Sizes and offsets of the banked streams, formula for formula as the
   reference host computes them (frt/host.py line numbers in comments)."""
@@ -197,9 +254,12 @@ def input_shifts(stencil: core.Stencil) -> Dict[str, int]:
   return stencil.produce_offsets()
 
 
-def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None):
+def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None,
+                 direct: bool = True):
   """(StreamDesc, {tag: ProgramSpec}) of `<app>_kernel` for `stencil`.  Tags:
-  `dense` (optional), `linear<V>`, `unwire_<input>`, `wire_<output>`."""
+  `dense` (optional), `linear<V>`, `unwire_<input>`, `wire_<output>` (absent
+  for an output the program writes in place).  `direct=False`: every output
+  through the shift + copy pass, as before round 5."""
   if stencil.param_stmts:
     raise util.SemanticError('stream mode does not support param tensors')
   if stencil.preserve_border:
@@ -208,7 +268,12 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None):
         'grid borders)')
   st = stencil
   table = st.symbol_table
-  flat = linearize(st)
+  # outputs stored at their wire positions by the program itself where that is
+  # possible (emit_late): no shift left for the copy pass, and no copy pass at
+  # all for an output on one bank
+  late = emit_late(st) if direct else None
+  run = late or st
+  flat = linearize(run)
   banks = {s.name: len(s.dram) for s in st.input_stmts + st.output_stmts}
   offsets = stencil_offsets(st)
   shifts = input_shifts(st)
@@ -224,7 +289,7 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None):
     desc.banks[t] = banks[n]
     desc.elem_size[t] = table[n].size_in_bytes
     desc.elems_per_cycle[t] = st.burst_width // table[n].width_in_bits * banks[n]
-    desc.shift[t] = shifts[n] if n in shifts else offsets[n]
+    desc.shift[t] = shifts[n] if n in shifts else (0 if late else offsets[n])
   specs: Dict[str, ProgramSpec] = {}
 
   def program_spec(tag, sten, opts, extent):
@@ -254,7 +319,7 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None):
     dense = st.dim >= 2 and st.tile_size[0] >= StreamProgram.DENSE_MIN_TILE0
   if dense and st.dim >= 2:
     try:
-      program_spec('dense', st, lower.LowerOptions(),
+      program_spec('dense', run, lower.LowerOptions(),
                    tuple(st.tile_size[:-1]) + (1 << 20,))
     except util.SodaError:
       pass
@@ -277,7 +342,9 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None):
                    table[s_.name].size_in_bytes))
   for s_ in st.output_stmts:
     nb, ct = banks[s_.name], table[s_.name].c_type
-    off = offsets[s_.name]
+    off = 0 if late else offsets[s_.name]
+    if nb == 1 and off == 0:
+      continue                 # the program writes the bank itself
     name = 'soda_wire_%s' % s_.name
     body = ['  const %s* __restrict__ dense = (const %s*)a.buf[0];' % (ct, ct),
             '  %s* bank = (%s*)a.buf[1 + k %% %d];' % (ct, ct, nb),
@@ -304,13 +371,13 @@ class StreamProgram:
   DENSE_MIN_TILE0 = 256
 
   def __init__(self, stencil: core.Stencil, device: int = 0,
-               dense: Optional[bool] = None):
+               dense: Optional[bool] = None, direct: bool = True):
     """`dense`: None = use the n-D marching kernels when the stream allows it
     and the tile is wide enough to fill them, True = whenever the stream
-    allows it, False = always the linear form."""
+    allows it, False = always the linear form.  `direct`: see stream_specs."""
     self.stencil = stencil
     self.device = device
-    self.desc, self.specs = stream_specs(stencil, dense)
+    self.desc, self.specs = stream_specs(stencil, dense, direct)
     self.banks = {s.name: len(s.dram)
                   for s in stencil.input_stmts + stencil.output_stmts}
     self.stencil_offset = stencil_offsets(stencil)   # a program constant
@@ -335,7 +402,7 @@ class StreamProgram:
     unw = (ctypes.c_void_p * d.num_inputs)(*[
         self._programs.get('unwire_%s' % n) for n in stencil.input_names])
     wir = (ctypes.c_void_p * d.num_outputs)(*[
-        self._programs['wire_%s' % n] for n in stencil.output_names])
+        self._programs.get('wire_%s' % n) for n in stencil.output_names])
     self._handle = ctypes.c_void_p()
     runtime.check(
         lib.soda_hip_stream_create(ctypes.byref(d), self._programs.get('dense'),

@@ -136,6 +136,98 @@ def test_wire_chain_as_dense_view(name, extent):
       assert np.array_equal(got[o], want[o])
 
 
+@pytest.mark.parametrize('name,extent,iterate', [
+    ('blur.soda', (2000, 12), None), ('blur.soda', (4500, 9), None),
+    ('blur.soda', (2000, 14), 3),                   # the field moves 3 x (2, 2)
+    ('jacobi2d.soda', (32, 12), None), ('jacobi2d.soda', (100, 9), None),
+    ('jacobi2d.soda', (32, 20), 5),
+    ('heat3d.soda', (70, 40, 7), None), ('sobel2d.soda', (32, 8), None),
+    ('denoise2d.soda', (32, 14), None),             # two inputs, delayed
+    ('coupled2d.soda', (32, 11), 1),                # two outputs, own offsets
+])
+def test_outputs_born_at_their_wire_positions(name, extent, iterate):
+  """`emit_late`: the program with every output's store index moved by the
+  window point of largest linear offset leaves, run PLAINLY (no shift, no
+  copy) as the causal 1-D form and as the n-D program on the dense view,
+  every cell the host reads back where the kernel contract wants it."""
+  from oracle import frt_layout, numpy_oracle
+  st = core.from_file(soda_path(name), iterate=iterate)
+  late = stream.emit_late(st)
+  assert late is not None
+  tile = st.tile_size
+  for s0, s1 in zip(st.output_stmts, late.output_stmts):
+    c = tuple(b - a for a, b in zip(s0.ref.idx, s1.ref.idx))
+    assert c in st.stencil_window_points(s0.name, iterate=1)
+    from soda_amd import util
+    assert util.serialize(c, tile) * st.iterate == stream.stencil_offsets(st)[
+        s0.name]
+  lay = stream.WireLayout(st, extent)
+  rng = np.random.default_rng(16)
+  ins = {}
+  for n, t in zip(st.input_names, st.input_types):
+    shape = tuple(extent[::-1])
+    ins[n] = (rng.random(shape).astype(t.np_name) if t.is_float else
+              rng.integers(-100, 100, shape).astype(t.np_name))
+  banks = frt_layout.scatter(lay, ins)
+  n = lay.cycle_count * lay.epc[st.input_names[0]]
+  streams = {}
+  for nme in st.input_names:
+    nb = lay.bank_count[nme]
+    s = np.zeros(n, banks[nme][0].dtype)
+    for b in range(nb):
+      s[b::nb] = banks[nme][b][:len(s[b::nb])]
+    po = st.produce_offsets()[nme] if len(st.input_names) > 1 else 0
+    if po:
+      s = np.concatenate([s[po:], np.zeros(po, s.dtype)])
+    streams[nme] = s
+  ref = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(st.output_names, st.output_types)}
+  frt_layout.gather(lay, frt_layout.kernel_on_streams(lay, banks), ref)
+  boxes = [st.valid_box(extent, o) for o in st.output_names]
+  lo = [max(b[0][d] for b in boxes) for d in range(st.dim)]
+  hi = [min(b[1][d] for b in boxes) for d in range(st.dim)]
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+
+  def check(out_streams):
+    out_banks = frt_layout.alloc(lay, st.output_names)
+    for o in st.output_names:
+      nb = lay.bank_count[o]
+      for b in range(nb):
+        out_banks[o][b][:len(out_streams[o][b::nb])] = out_streams[o][b::nb]
+    got = {o: np.zeros_like(ref[o]) for o in ref}
+    frt_layout.gather(lay, out_banks, got)
+    for o in st.output_names:
+      assert ref[o][idx].any()
+      if len(st.output_names) == 1:
+        assert np.array_equal(got[o], ref[o]), o
+      else:
+        assert np.array_equal(got[o][idx], ref[o][idx]), o
+
+  # the causal 1-D form
+  check(numpy_oracle.run(stream.linearize(late), streams))
+  # the n-D program on the dense view
+  block = int(np.prod(tile[:-1]))
+  if block % lay.epc[st.input_names[0]] == 0 and st.stencil_distance >= block:
+    rows = n // block
+    view = tuple(tile[:-1]) + (rows,)
+    out_nd = numpy_oracle.run(
+        late, {k: v[:rows * block].reshape(view[::-1])
+               for k, v in streams.items()})
+    flat = {}
+    for o in st.output_names:
+      flat[o] = np.zeros(n, out_nd[o].dtype)
+      flat[o][:rows * block] = out_nd[o].reshape(-1)
+    check(flat)
+  else:
+    assert name == 'never', 'every case here has a dense view'
+
+
+def test_several_circulating_tensors_keep_the_copy_pass():
+  st = core.from_file(soda_path('coupled2d.soda'))
+  assert st.iterate > 1 and len(st.output_names) == 2
+  assert stream.emit_late(st) is None
+
+
 @pytest.mark.parametrize('name,extent', [('denoise2d.soda', (32, 14)),
                                          ('coupled2d.soda', (32, 11))])
 def test_wire_chain_with_several_inputs(name, extent):

@@ -16,11 +16,14 @@ def main():
   ap.add_argument('--soda', default='tests/golden/soda/blur.soda')
   ap.add_argument('--extent', type=int, nargs='+', default=[2000, 16384])
   ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--tile', type=int, nargs='+', default=None,
+                  help='tile size of dimensions 0..dim-2 instead of the file\'s')
+  ap.add_argument('--iterate', type=int, default=None)
   ap.add_argument('--host', action='store_true',
                   help='also time soda_hip_stream_run_host on pageable banks')
   args = ap.parse_args()
   from soda_amd import core, runtime, stream
-  st = core.from_file(args.soda)
+  st = core.from_file(args.soda, iterate=args.iterate, tile_size=args.tile)
   lay = stream.WireLayout(st, args.extent)
   lib = runtime.library()
   table = st.symbol_table
@@ -42,8 +45,9 @@ def main():
   cells = 1
   for e in args.extent:
     cells *= e
-  for mode in ('dense', 'linear'):
-    prog = stream.StreamProgram(st, dense=mode == 'dense')
+  for mode, direct in (('dense', True), ('dense', False), ('linear', True),
+                       ('linear', False)):
+    prog = stream.StreamProgram(st, dense=mode == 'dense', direct=direct)
     for _ in range(3):
       prog.run_banked_device(outs, ins, lay.cycle_count)
     runtime.synchronize()
@@ -55,7 +59,11 @@ def main():
     runtime.synchronize()
     ms = e0.elapsed_ms(e1) / args.steps
     print(json.dumps({'soda': os.path.basename(args.soda), 'extent': args.extent,
-                      'mode': prog.last_mode, 'ms_per_call': round(ms, 4),
+                      'mode': prog.last_mode,
+                      'outputs': 'stored in place' if direct and not any(
+                          t.startswith('wire_') for t in prog.specs)
+                      else 'shift + copy pass',
+                      'ms_per_call': round(ms, 4),
                       'cells_iters_per_s': cells * st.iterate / ms * 1e3,
                       'tiles': lay.tiles}))
     if args.host:
