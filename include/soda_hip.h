@@ -622,7 +622,11 @@ int soda_hip_stream_create(const soda_hip_stream_desc_t* desc,
 int soda_hip_stream_destroy(soda_hip_stream_t* stream);
 /* Bank pointers in the order of the reference kernel's ports: all banks of
  * output 0, output 1, ...; then all banks of input 0, input 1, ....  Device
- * pointers, asynchronous on `hip_stream`. */
+ * pointers, asynchronous on `hip_stream`.  A tensor on ONE bank is read /
+ * written in place by the program and must be 16-byte aligned (INVALID
+ * otherwise; hipMalloc and the reference host's aligned_alloc(4096) are);
+ * banks of a tensor on several may start anywhere (the copy kernels move 16
+ * bytes per bank per thread when all are aligned, single elements if not). */
 int soda_hip_stream_run_device(soda_hip_stream_t* stream,
                                void* const* out_banks,
                                const void* const* in_banks,

@@ -1452,6 +1452,10 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
       if (!in_banks[bank0 + b])
         return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL input bank");
     if (nb == 1 && d.shift[i] == 0) {
+      if (reinterpret_cast<uintptr_t>(in_banks[bank0]) & 15)
+        return fail(SODA_HIP_ERR_INVALID,
+                    "stream_run: a bank the program reads in place must be "
+                    "16-byte aligned");
       din[i] = in_banks[bank0];     // the bank IS the dense stream
     } else {
       if (int rc = ensure(s->dense_in[i], (size_t)n * d.elem_size[i])) return rc;
@@ -1470,6 +1474,10 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
       if (!out_banks[bank0 + b])
         return fail(SODA_HIP_ERR_INVALID, "stream_run: NULL output bank");
     if (!s->wire[o]) {
+      if (reinterpret_cast<uintptr_t>(out_banks[bank0]) & 15)
+        return fail(SODA_HIP_ERR_INVALID,
+                    "stream_run: a bank the program writes in place must be "
+                    "16-byte aligned");
       dout[o] = out_banks[bank0];   // born at its wire position, in place
       continue;
     }

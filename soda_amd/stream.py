@@ -209,6 +209,76 @@ extern "C" __global__ void __launch_bounds__(256) %(name)s(soda_hip_kargs_t a) {
 }
 """
 
+# The same with 16 bytes per bank per thread: one vector load (store) per bank,
+# the interleave done in registers, NB vector stores (loads) on the dense side.
+# Only for whole groups of V x NB elements inside the stream; the last, partial
+# group goes element by element.  `lead` = elements the bank pointers are
+# advanced by (an input the host delayed by a multiple of V x NB elements).
+_WIRE_VEC_SRC = """
+extern "C" __global__ void __launch_bounds__(256) %(name)s(soda_hip_kargs_t a) {
+  typedef %(ct)s soda_v __attribute__((ext_vector_type(%(V)d)));
+  const int64_t n = a.extent[0];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k0 = t * %(group)d;
+  if (k0 >= n) return;
+  %(dense_decl)s
+  uint64_t soda_low = 0;      // the caller's banks: 16-byte aligned, or slow
+  for (int b = 0; b < %(NB)d + 1; ++b) soda_low |= (uint64_t)a.buf[b];
+  if (k0 + %(group)d + %(lead)d * %(NB)d <= n && (soda_low & 15) == 0) {
+%(vec_body)s
+  } else {
+    const int64_t end = k0 + %(group)d < n ? k0 + %(group)d : n;
+    for (int64_t k = k0; k < end; ++k) {
+%(tail_body)s
+    }
+  }
+}
+"""
+
+
+def _vec_copy_source(name: str, ct: str, elem: int, nb: int, lead: int,
+                     to_dense: bool) -> Optional[str]:
+  """Text of the vector form of unwire_<in> (to_dense) / wire_<out>, or None
+  where 16 bytes per bank per thread do not divide evenly."""
+  if elem not in (1, 2, 4, 8) or nb > 8:
+    return None
+  V = 16 // elem
+  if lead % V:
+    return None
+  L = []
+  if to_dense:
+    decl = '%s* __restrict__ dense = (%s*)a.buf[%d];' % (ct, ct, nb)
+    for b in range(nb):
+      L.append('    const soda_v r%d = *(const soda_v*)((const %s*)a.buf[%d] + '
+               't * %d + %d);' % (b, ct, b, V, lead))
+    for o in range(nb):
+      elems = ['r%d[%d]' % ((o * V + e) % nb, (o * V + e) // nb)
+               for e in range(V)]
+      L.append('    { soda_v w; %s' % ' '.join(
+          'w[%d] = %s;' % (e, x) for e, x in enumerate(elems)))
+      L.append('      *(soda_v*)(dense + k0 + %d) = w; }' % (o * V))
+    tail = ['      const int64_t src = k + %d;' % (lead * nb),
+            '      dense[k] = src < n ? ((const %s*)a.buf[src %% %d])[src / %d]'
+            ' : (%s)0;' % (ct, nb, nb, ct)]
+  else:
+    decl = 'const %s* __restrict__ dense = (const %s*)a.buf[0];' % (ct, ct)
+    for o in range(nb):
+      L.append('    const soda_v r%d = *(const soda_v*)(dense + k0 + %d);' %
+               (o, o * V))
+    for b in range(nb):
+      elems = ['r%d[%d]' % ((j * nb + b) // V, (j * nb + b) % V)
+               for j in range(V)]
+      L.append('    { soda_v w; %s' % ' '.join(
+          'w[%d] = %s;' % (e, x) for e, x in enumerate(elems)))
+      L.append('      *(soda_v*)((%s*)a.buf[%d] + t * %d) = w; }' %
+               (ct, 1 + b, V))
+    tail = ['      ((%s*)a.buf[1 + k %% %d])[k / %d] = dense[k];' % (ct, nb, nb)]
+  return _WIRE_VEC_SRC % dict(name=name, ct=ct, V=V, NB=nb, group=V * nb,
+                              lead=lead, dense_decl=decl,
+                              vec_body='\n'.join(L),
+                              tail_body='\n'.join(tail))
+
+
 StreamDesc = runtime.StreamDesc
 
 
@@ -222,7 +292,8 @@ class ProgramSpec:
     self.kernel_names = list(kernel_names)
 
 
-def _copy_plan(name: str, n_in: int, n_out: int, elem: int) -> 'runtime.Plan':
+def _copy_plan(name: str, n_in: int, n_out: int, elem: int,
+               per_block: int = 256) -> 'runtime.Plan':
   plan = runtime.Plan()
   plan.abi_version = runtime.ABI_VERSION
   plan.dim = 1
@@ -233,7 +304,7 @@ def _copy_plan(name: str, n_in: int, n_out: int, elem: int) -> 'runtime.Plan':
   plan.kernels[0].name = name.encode()
   plan.kernels[0].block[0] = 256
   plan.kernels[0].block[1] = plan.kernels[0].block[2] = 1
-  plan.kernels[0].tile[0] = 256
+  plan.kernels[0].tile[0] = per_block       # stream elements per block
   for d in range(1, runtime.MAX_DIM):
     plan.kernels[0].tile[d] = 1
   plan.kernels[0].window_extra = -1
@@ -319,7 +390,9 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None,
     dense = st.dim >= 2 and st.tile_size[0] >= StreamProgram.DENSE_MIN_TILE0
   if dense and st.dim >= 2:
     try:
-      program_spec('dense', run, lower.LowerOptions(),
+      # (iterated programs: the depths the n-D entry offers; lower() clips
+      # them to `iterate`, the library mixes them per stream length)
+      program_spec('dense', run, lower.LowerOptions(fuse=lower.DEFAULT_FUSE),
                    tuple(st.tile_size[:-1]) + (1 << 20,))
     except util.SodaError:
       pass
@@ -337,9 +410,12 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None,
             '  const %s* bank = (const %s*)a.buf[src %% %d];' % (ct, ct, nb),
             '  dense[k] = src < a.extent[0] ? bank[src / %d] : (%s)0;' %
             (nb, ct)]
-    chunks.append(_WIRE_SRC % dict(name=name, body='\n'.join(body)))
-    copies.append(('unwire_%s' % s_.name, name, nb, 1,
-                   table[s_.name].size_in_bytes))
+    elem = table[s_.name].size_in_bytes
+    vec = _vec_copy_source(name, ct, elem, nb, shift // nb, True) \
+        if shift % nb == 0 else None
+    chunks.append(vec or _WIRE_SRC % dict(name=name, body='\n'.join(body)))
+    copies.append(('unwire_%s' % s_.name, name, nb, 1, elem,
+                   256 * (16 // elem) * nb if vec else 256))
   for s_ in st.output_stmts:
     nb, ct = banks[s_.name], table[s_.name].c_type
     off = 0 if late else offsets[s_.name]
@@ -350,12 +426,15 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None,
             '  %s* bank = (%s*)a.buf[1 + k %% %d];' % (ct, ct, nb),
             '  bank[k / %d] = k >= %d ? dense[k - %d] : (%s)0;' %
             (nb, off, off, ct)]
-    chunks.append(_WIRE_SRC % dict(name=name, body='\n'.join(body)))
-    copies.append(('wire_%s' % s_.name, name, 1, nb,
-                   table[s_.name].size_in_bytes))
+    elem = table[s_.name].size_in_bytes
+    vec = _vec_copy_source(name, ct, elem, nb, 0, False) if off == 0 else None
+    chunks.append(vec or _WIRE_SRC % dict(name=name, body='\n'.join(body)))
+    copies.append(('wire_%s' % s_.name, name, 1, nb, elem,
+                   256 * (16 // elem) * nb if vec else 256))
   source = '\n'.join(chunks)
-  for tag, name, n_in, n_out, elem in copies:
-    specs[tag] = ProgramSpec(tag, source, _copy_plan(name, n_in, n_out, elem),
+  for tag, name, n_in, n_out, elem, per_block in copies:
+    specs[tag] = ProgramSpec(tag, source,
+                             _copy_plan(name, n_in, n_out, elem, per_block),
                              [name])
   return desc, specs
 

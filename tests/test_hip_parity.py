@@ -723,6 +723,16 @@ STREAM_CASES = [
     ('sobel2d.soda', None, (32, 8), None, 'dense'),    # three stages, int16
     ('jacobi2d.soda', 'input dram 0.1 float: t1(32, *)', (32, 12),
      'output dram 2.3 float:', 'dense'),              # two banks each side
+    ('jacobi2d.soda', 'input dram 0.1 float: t1(32, *)', (32, 13),
+     'output dram 2.3 float:', 'linear'),
+    ('blur.soda', 'input dram 0.1.2.3 uint16: input(2048, *)', (2048, 20),
+     'output dram 0.1.2.3 uint16:', 'dense'),         # four banks, 8 cells per 16 B
+    ('blur.soda', 'input dram 0.1.2.3 uint16: input(2000, *)', (2000, 20),
+     'output dram 0.1.2.3 uint16:', 'fallback'),      # 2000 % 64 != 0
+    ('blur.soda', 'input dram 0.1.2 uint16: input(1008, *)', (1008, 9),
+     'output dram 1.2.3 uint16:', 'dense'),           # three
+    ('heat3d.soda', 'input dram 0.1 float: in(32, 32, *)', (32, 32, 9),
+     'output dram 0.1 float:', 'dense'),
     # several inputs: the host delays each by its produce offset (f by two
     # rows behind u in denoise2d); two outputs in coupled2d
     ('denoise2d.soda', None, (32, 14), None, 'dense'),
@@ -743,7 +753,7 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
   if in_decl:
     text = re.sub(r'input dram [^\n]*', in_decl, text)
   if out_decl:
-    text = re.sub(r'output dram \d+ float:', out_decl, text)
+    text = re.sub(r'output dram [\d.]+ \w+:', out_decl, text)
   stencil = core.from_text(text)
   inputs = _inputs(stencil, extent, seed=5)
   layout = stream.WireLayout(stencil, extent)
@@ -803,6 +813,46 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
     assert np.array_equal(got[o][idx], want[o][idx]), o
     if len(stencil.output_names) == 1:
       assert np.array_equal(got[o], want[o]), o
+
+
+@pytest.mark.gpu
+def test_wire_banks_at_any_address(built):
+  """The bank copy kernels move 16 bytes per bank per thread when every bank
+  is 16-byte aligned, element by element otherwise: device banks that start 4
+  bytes into an allocation give the same streams."""
+  import re
+  import torch
+  from soda_amd import core, stream
+  text = open(soda_path('jacobi2d.soda')).read()
+  text = re.sub(r'input dram [^\n]*', 'input dram 0.1 float: t1(32, *)', text)
+  text = re.sub(r'output dram [\d.]+ \w+:', 'output dram 2.3 float:', text)
+  stencil = core.from_text(text)
+  extent = (32, 45)
+  layout = stream.WireLayout(stencil, extent)
+  per_bank = layout.buf_elems['t1'] // 2
+  rng = np.random.default_rng(3)
+  host = [rng.random(per_bank, dtype=np.float32) for _ in range(2)]
+  prog = stream.StreamProgram(stencil, dense=True)
+  try:
+    results = []
+    for lead in (0, 1):
+      ins = [torch.zeros(per_bank + 4, device='cuda') for _ in range(2)]
+      outs = [torch.full((per_bank + 4,), -7.0, device='cuda') for _ in range(2)]
+      for t, h in zip(ins, host):
+        t[lead:lead + per_bank] = torch.from_numpy(h).cuda()
+      prog.run_banked_device(
+          {'t0': [t.data_ptr() + 4 * lead for t in outs]},
+          {'t1': [t.data_ptr() + 4 * lead for t in ins]}, layout.cycle_count,
+          stream=torch.cuda.current_stream().cuda_stream)
+      torch.cuda.synchronize()
+      for t in outs:   # nothing outside the bank
+        assert (t[:lead] == -7).all() and (t[lead + per_bank:] == -7).all()
+      results.append([t[lead:lead + per_bank].cpu().numpy() for t in outs])
+  finally:
+    prog.close()
+  for a, b in zip(*results):
+    assert np.array_equal(a, b)
+  assert any(a.any() for a in results[0])
 
 
 @pytest.mark.parametrize('name,iterate,fuse,pipe,extent', [

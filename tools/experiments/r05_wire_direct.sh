@@ -14,4 +14,6 @@ python tools/streambench.py --soda $g/jacobi2d.soda --tile 8192 --iterate 100 --
 python tools/streambench.py --soda $g/heat3d.soda --extent 32 32 65536 >> $out
 python tools/streambench.py --soda $g/heat3d.soda --tile 512 512 --iterate 2 --extent 512 512 512 >> $out
 python tools/streambench.py --soda $g/sobel2d.soda --tile 4096 --extent 4096 8192 >> $out
+python tools/streambench.py --soda $g/blur.soda --tile 16384 --banks 4 --extent 16384 16384 >> $out
+python tools/streambench.py --soda $g/jacobi2d.soda --tile 8192 --banks 2 --iterate 1 --extent 8192 8192 >> $out
 cat $out

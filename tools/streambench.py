@@ -19,11 +19,20 @@ def main():
   ap.add_argument('--tile', type=int, nargs='+', default=None,
                   help='tile size of dimensions 0..dim-2 instead of the file\'s')
   ap.add_argument('--iterate', type=int, default=None)
+  ap.add_argument('--banks', type=int, default=None,
+                  help='DRAM banks of every tensor instead of the file\'s')
   ap.add_argument('--host', action='store_true',
                   help='also time soda_hip_stream_run_host on pageable banks')
   args = ap.parse_args()
   from soda_amd import core, runtime, stream
-  st = core.from_file(args.soda, iterate=args.iterate, tile_size=args.tile)
+  if args.banks:
+    import re
+    dram = '.'.join(map(str, range(args.banks)))
+    text = re.sub(r'(input|output) dram [\d.]+', r'\1 dram ' + dram,
+                  open(args.soda).read())
+    st = core.from_text(text, iterate=args.iterate, tile_size=args.tile)
+  else:
+    st = core.from_file(args.soda, iterate=args.iterate, tile_size=args.tile)
   lay = stream.WireLayout(st, args.extent)
   lib = runtime.library()
   table = st.symbol_table
@@ -60,12 +69,14 @@ def main():
     ms = e0.elapsed_ms(e1) / args.steps
     print(json.dumps({'soda': os.path.basename(args.soda), 'extent': args.extent,
                       'mode': prog.last_mode,
-                      'outputs': 'stored in place' if direct and not any(
-                          t.startswith('wire_') for t in prog.specs)
-                      else 'shift + copy pass',
+                      'outputs': ('shift + copy pass' if not direct else
+                                  'stored late, 16-byte interleave pass' if any(
+                                      t.startswith('wire_') for t in prog.specs)
+                                  else 'stored in place'),
                       'ms_per_call': round(ms, 4),
                       'cells_iters_per_s': cells * st.iterate / ms * 1e3,
-                      'tiles': lay.tiles}))
+                      'tiles': lay.tiles,
+                      'banks': max(lay.bank_count.values())}))
     if args.host:
       # <app>_kernel on HOST banks, as the generated host calls it
       # (SODA_CPP_BINDING): pageable arrays of the reference's sizes
