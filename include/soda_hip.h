@@ -633,7 +633,11 @@ int soda_hip_stream_run_device(soda_hip_stream_t* stream,
                                uint64_t coalesced_data_num, void* hip_stream);
 /* The same on host buffers sized as the reference host allocates them
  * (coalesced_data_num x elems_per_cycle / banks elements per bank): what
- * <app>_kernel receives under SODA_CPP_BINDING.  Synchronous. */
+ * <app>_kernel receives under SODA_CPP_BINDING.  Synchronous.  Where every
+ * tensor is on one bank, in place, and the stream is a dense array of rows,
+ * the banks go through soda_hip_run_host_box on the n-D program (bands:
+ * copy-in, kernels and copy-out overlapped; SODA_HIP_STREAM_NO_BANDS=1: whole
+ * banks in, run, whole banks out, as for every other stream). */
 int soda_hip_stream_run_host(soda_hip_stream_t* stream, void* const* out_banks,
                              const void* const* in_banks,
                              uint64_t coalesced_data_num);

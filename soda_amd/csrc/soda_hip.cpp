@@ -1431,6 +1431,26 @@ int soda_hip_stream_destroy(soda_hip_stream_t* s) {
 
 int soda_hip_stream_last_mode(soda_hip_stream_t* s) { return s ? s->last_mode : 0; }
 
+// Dense view: a stream of n elements is an array of extent (tile..., rows) iff
+// every tile starts on a row-block boundary -- a tile occupies
+// round_up(block * extent_last, epc) elements (frt/host.py:137-142), so for any
+// extent iff block % epc == 0 -- and the void tail (kStencilDistance elements,
+// :151-162) covers the partial last row the view drops.
+static bool dense_view(const soda_hip_stream* s, int64_t n, int32_t* ext) {
+  const soda_hip_stream_desc_t& d = s->desc;
+  if (s->dense_failed || d.dim < 2) return false;
+  int64_t block = 1;
+  for (int t = 0; t < d.dim - 1; ++t) block *= d.tile[t];
+  const int64_t rows = n / block;
+  if (rows < 1 || d.stencil_distance < block ||
+      block % d.elems_per_cycle[0] != 0)
+    return false;
+  for (int t = 0; t < SODA_HIP_MAX_DIM; ++t) ext[t] = 1;
+  for (int t = 0; t < d.dim - 1; ++t) ext[t] = d.tile[t];
+  ext[d.dim - 1] = (int32_t)rows;
+  return true;
+}
+
 int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
                                const void* const* in_banks,
                                uint64_t coalesced_data_num, void* hip_stream) {
@@ -1491,21 +1511,11 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
                              static_cast<hipStream_t>(hip_stream)));
     dout[o] = s->dense_out[o].ptr;
   }
-  // 2. the program.  Dense view: the stream is an array of extent (tile...,
-  // rows) iff every tile starts on a row-block boundary -- a tile occupies
-  // round_up(block * extent_last, epc) elements (frt/host.py:137-142), so for
-  // any extent iff block % epc == 0 -- and the void tail (kStencilDistance
-  // elements, :151-162) covers the partial last row the view drops.
+  // 2. the program, on the dense view where there is one
   bool done = false;
-  if (!s->dense_failed && d.dim >= 2) {
-    int64_t block = 1;
-    for (int t = 0; t < d.dim - 1; ++t) block *= d.tile[t];
-    const int64_t rows = n / block;
-    if (rows >= 1 && d.stencil_distance >= block &&
-        block % d.elems_per_cycle[0] == 0) {
-      int32_t ext[SODA_HIP_MAX_DIM] = {1, 1, 1, 1};
-      for (int t = 0; t < d.dim - 1; ++t) ext[t] = d.tile[t];
-      ext[d.dim - 1] = (int32_t)rows;
+  {
+    int32_t ext[SODA_HIP_MAX_DIM];
+    if (dense_view(s, n, ext)) {
       int rc = soda_hip_run_device(s->dense, dout.data(), din.data(), ext,
                                    d.iterate, hip_stream);
       if (rc == SODA_HIP_OK) {
@@ -1543,10 +1553,52 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
   if (!s || !out_banks || !in_banks)
     return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL argument");
   const soda_hip_stream_desc_t& d = s->desc;
-  // The banks are the generated host's pageable `aligned_alloc` buffers
-  // (ref frt/host.py:165-178): they travel through the pinned rings and the
-  // worker threads of the host-array entry (soda_host.cpp), on one stream with
-  // the kernels, instead of synchronous pageable copies.
+  // Every tensor on one bank that the program reads / writes in place, and the
+  // stream a dense array of rows: the caller's banks ARE host arrays of the
+  // n-D program, and the call is the host-array entry's (soda_host.cpp) --
+  // copy-in, kernels and copy-out overlapped in bands along the rows.  The
+  // elements of the partial last row stay as the caller left them (void tail).
+  {
+    bool in_place = !getenv("SODA_HIP_STREAM_NO_BANDS");
+    for (int i = 0; i < d.num_inputs; ++i)
+      in_place = in_place && d.banks[i] == 1 && d.shift[i] == 0;
+    for (int o = 0; o < d.num_outputs; ++o) in_place = in_place && !s->wire[o];
+    const uint64_t n64 = coalesced_data_num * (uint64_t)d.elems_per_cycle[0];
+    int32_t ext[SODA_HIP_MAX_DIM];
+    if (in_place && n64 >= 1 && n64 < (1ull << 31) &&
+        dense_view(s, (int64_t)n64, ext)) {
+      int32_t stride[SODA_HIP_MAX_DIM];
+      int64_t run = 1;
+      for (int t = 0; t < SODA_HIP_MAX_DIM; ++t) {
+        stride[t] = run > INT32_MAX ? INT32_MAX : (int32_t)run;   // (t >= dim: unread)
+        run *= ext[t];
+      }
+      std::vector<soda_hip_host_tensor_t> tin(d.num_inputs), tout(d.num_outputs);
+      bool null_bank = false;
+      for (int i = 0; i < d.num_inputs; ++i) {
+        tin[i] = {const_cast<void*>(in_banks[i]), ext, stride, nullptr};
+        null_bank = null_bank || !in_banks[i];
+      }
+      for (int o = 0; o < d.num_outputs; ++o) {
+        tout[o] = {out_banks[o], ext, stride, nullptr};
+        null_bank = null_bank || !out_banks[o];
+      }
+      if (null_bank)
+        return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL bank");
+      int rc = soda_hip_run_host_box(s->dense, tin.data(), tout.data(),
+                                     d.iterate, nullptr, nullptr);
+      if (rc == SODA_HIP_OK) {
+        s->last_mode = 1;
+        return rc;
+      }
+      if (rc != SODA_HIP_ERR_INVALID) return rc;
+      // INVALID: this extent does not suit the dense kernels; the long way
+    }
+  }
+  // Otherwise the banks -- the generated host's pageable `aligned_alloc`
+  // buffers (ref frt/host.py:165-178) -- travel whole through the pinned rings
+  // and the worker threads of the host-array entry, on one stream with the
+  // kernels.
   soda_hip_program* owner = s->linear.back();
   hipStream_t stream = nullptr;
   if (int rc = host_stream(owner, &stream)) return rc;
