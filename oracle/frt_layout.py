@@ -154,3 +154,49 @@ def kernel_on_streams(layout, in_banks):
     for b in range(nb):
       out_banks[o][b][:len(wire[b::nb])] = wire[b::nb]
   return out_banks
+
+
+def kernel_on_dense_view(layout, in_banks):
+  """The kernel contract's OTHER legal reading, or None: where a tile's row
+  block is a whole number of bursts the stream is a dense (tile..., rows) array
+  (tests/test_stream.py test_wire_chain_as_dense_view) and the kernel may run
+  the n-D program on it.  Every cell whose window lies inside its tile gets the
+  same value as from kernel_on_streams; a cell the host gathers although ITS
+  output's window leaves the tile (several outputs with different windows:
+  the host gathers all of them over the region of the program's window,
+  host.py:357-375) wraps into the neighbouring rows in the 1-D form and reads
+  outside the array in this one -- unspecified in both.  Cells where the two
+  restatements differ are therefore exactly the ones no kernel can be held to.
+  Returns banks like kernel_on_streams."""
+  from oracle import numpy_oracle
+  st = layout.stencil
+  epc = layout.epc[st.input_names[0]]
+  n = layout.cycle_count * epc
+  block = 1
+  for t in st.tile_size[:-1]:
+    block *= t
+  if st.dim < 2 or block % epc or st.stencil_distance < block or n < block:
+    return None
+  rows = n // block
+  view = tuple(st.tile_size[:-1]) + (rows,)
+  dense = {}
+  for name in st.input_names:
+    nb = layout.bank_count[name]
+    s = np.zeros(n, in_banks[name][0].dtype)
+    for b in range(nb):
+      s[b::nb] = in_banks[name][b][:len(s[b::nb])]
+    po = st.produce_offsets()[name] if len(st.input_names) > 1 else 0
+    if po:
+      s = np.concatenate([s[po:], np.zeros(po, s.dtype)])
+    dense[name] = s[:rows * block].reshape(view[::-1])
+  out_nd = numpy_oracle.run(st, dense)
+  out_banks = alloc(layout, st.output_names)
+  for o in st.output_names:
+    off, nb = layout.stencil_offset[o], layout.bank_count[o]
+    flat = np.zeros(n, out_nd[o].dtype)
+    flat[:rows * block] = out_nd[o].reshape(-1)
+    wire = np.zeros(n, flat.dtype)
+    wire[off:] = flat[:n - off]
+    for b in range(nb):
+      out_banks[o][b][:len(wire[b::nb])] = wire[b::nb]
+  return out_banks

@@ -79,6 +79,12 @@ def stencil_offsets(stencil: core.Stencil) -> Dict[str, int]:
           'window' % s.name)
     out[s.name] = core.get_stencil_distance(pts, tile) - util.serialize(
         core.get_stencil_window_offset(pts), tile)
+    if out[s.name] < 0:
+      # (every tap behind the cell: the reference host would gather such an
+      # output from in front of its buffer, host.py:401-424)
+      raise util.SemanticError(
+          'wire format: output `%s` reads only cells behind it (stencil '
+          'offset %d < 0)' % (s.name, out[s.name]))
   return out
 
 

@@ -287,3 +287,49 @@ def test_windows_wider_than_a_tile_are_refused():
                       'output float: b(0, 0) = %s\n' % taps)
   with pytest.raises(util.SemanticError, match='more than a tile'):
     stream.WireLayout(st, (100, 20))
+
+
+def test_outputs_that_only_look_back_are_refused():
+  """Every tap behind the cell: the stencil offset (largest linear offset of
+  the window) is negative and the reference host would gather the output from
+  in front of its buffer (frt/host.py:401-424).  Refused by name (the scan met
+  it as a shape error inside the host restatement)."""
+  from soda_amd import core, stream, util
+  st = core.from_text('kernel: k\nburst width: 64\nunroll factor: 2\n'
+                      'iterate: 1\ninput float: a(32, *)\n'
+                      'output float: b(0, 0) = a(-1, 0) + a(0, -1)\n')
+  with pytest.raises(util.SemanticError, match='behind'):
+    stream.WireLayout(st, (30, 20))
+  with pytest.raises(util.SemanticError, match='behind'):
+    stream.stream_specs(st)
+
+
+def test_cells_no_kernel_can_be_held_to():
+  """Two outputs with different windows on several tiles: the host gathers
+  both over the region of the program's window (frt/host.py:357-375), so the
+  output with the wider window of its own is read at tile-edge cells where the
+  1-D form wraps into the next row and the dense form reads outside the array.
+  The two restatements of the contract differ exactly there
+  (tools/fuzz_scan.py wire, seed 333)."""
+  from oracle import frt_layout
+  st = core.from_text(
+      'kernel: k\nburst width: 64\nunroll factor: 2\niterate: 1\n'
+      'input int32: a(32, *)\n'
+      'output int32: p(0, 0) = a(-2, -2) + a(1, 2)\n'
+      'output int32: q(0, 0) = a(1, -1) + a(2, 2)\n')
+  extent = (122, 27)
+  lay = stream.WireLayout(st, extent)
+  assert lay.tiles == 5
+  rng = np.random.default_rng(2)
+  banks = frt_layout.scatter(
+      lay, {'a': rng.integers(-99, 99, extent[::-1]).astype(np.int32)})
+  refs = []
+  for banks_out in (frt_layout.kernel_on_streams(lay, banks),
+                    frt_layout.kernel_on_dense_view(lay, banks)):
+    got = {o: np.zeros(extent[::-1], np.int32) for o in st.output_names}
+    frt_layout.gather(lay, banks_out, got)
+    refs.append(got)
+  assert np.array_equal(refs[0]['p'], refs[1]['p'])
+  cols = sorted(set(np.argwhere(refs[0]['q'] != refs[1]['q'])[:, 1].tolist()))
+  # in-tile column 30 of every tile (tiles step by 32 - 4 + 1 = 29 columns)
+  assert cols == [30, 59, 88, 117]

@@ -304,8 +304,22 @@ def wire_scan(first, last):
                                                   str(e)[:200]), flush=True)
       continue
     idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    # several outputs on several tiles: the host gathers every output over the
+    # region of the PROGRAM's window, so an output with a wider window of its
+    # own is read at tile-edge cells it cannot be computed at -- the 1-D form
+    # wraps into the next row there, the dense form reads outside the array
+    # (seed 333).  No kernel can be held to those: where the two restatements
+    # of the contract differ, the cell is not compared.
+    held = {o: np.ones(got[o][idx].shape, bool) for o in got}
+    if len(stencil.output_names) > 1 and layout.tiles > 1:
+      other = frt_layout.kernel_on_dense_view(layout, in_banks)
+      if other is not None:
+        ref2 = {o: np.zeros_like(got[o]) for o in got}
+        frt_layout.gather(layout, other, ref2)
+        held = {o: ref[o][idx] == ref2[o][idx] for o in got}
     bad = [o for o in stencil.output_names
-           if not np.array_equal(got[o][idx], ref[o][idx], equal_nan=True)]
+           if not np.array_equal(got[o][idx][held[o]], ref[o][idx][held[o]],
+                                 equal_nan=True)]
     # (several outputs: the host gathers each with ITS stencil offset over the
     # region of the program's window, and where the outputs' windows differ
     # the streams' cells and the n-D cells part ways -- the reference's layout,
