@@ -333,3 +333,34 @@ def test_cells_no_kernel_can_be_held_to():
   cols = sorted(set(np.argwhere(refs[0]['q'] != refs[1]['q'])[:, 1].tolist()))
   # in-tile column 30 of every tile (tiles step by 32 - 4 + 1 = 29 columns)
   assert cols == [30, 59, 88, 117]
+
+
+def test_delays_are_right_only_on_arrays_one_tile_wide():
+  """The reference host delays an input in the CALLER's coordinates
+  (data[max(0, original_offset - produce_offset)], frt/host.py:241-246) by an
+  offset that counts stream elements, i.e. TILE rows (core.py:371-426).  On an
+  array exactly one tile wide the kernel contract gives the caller the n-D
+  result (test_wire_chain_with_several_inputs); on a narrower one the delayed
+  input arrives misplaced and it does not -- an upstream defect this backend
+  reproduces rather than repairs (tools/fuzz_scan.py wire,
+  seeds 1159 / 1165 / 1419)."""
+  from oracle import frt_layout, numpy_oracle
+  st = core.from_file(soda_path('denoise2d.soda'))
+  assert st.produce_offsets() == {'f': 64, 'u': 0} and st.tile_size[0] == 32
+  agree = {}
+  for extent in ((32, 14), (28, 14)):
+    lay = stream.WireLayout(st, extent)
+    assert lay.tiles == 1
+    rng = np.random.default_rng(8)
+    ins = {n: rng.random(tuple(extent[::-1])).astype(t.np_name)
+           for n, t in zip(st.input_names, st.input_types)}
+    got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+           for o, t in zip(st.output_names, st.output_types)}
+    frt_layout.gather(lay, frt_layout.kernel_on_streams(
+        lay, frt_layout.scatter(lay, ins)), got)
+    want = numpy_oracle.run(st, ins)
+    lo, hi = st.valid_box(extent)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    o = st.output_names[0]
+    agree[extent[0]] = np.array_equal(got[o][idx], want[o][idx])
+  assert agree == {32: True, 28: False}
