@@ -815,6 +815,60 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
       assert np.array_equal(got[o], want[o]), o
 
 
+@pytest.mark.parametrize('name,tile,extent,iterate', [
+    ('blur.soda', None, (2000, 700), None),
+    ('jacobi2d.soda', (256,), (256, 1500), 6),     # 6 x (0, 1) late, 12 ghost rows
+    ('heat3d.soda', (64, 32), (64, 32, 400), 2),
+    ('sobel2d.soda', (512,), (512, 900), None),
+])
+def test_wire_host_banks_in_bands(built, monkeypatch, capfd, name, tile, extent,
+                                  iterate):
+  """<app>_kernel on host banks, every tensor in place on the dense view: the
+  call goes through the host-array entry, here forced into bands of 16 KiB
+  chunks (copy-in, kernels, copy-out overlapped; window runs with iterate x
+  reach ghost rows on the late program's one-sided window) -- the same cells
+  as the n-D oracle, and the same banks as one whole run."""
+  from soda_amd import core, stream
+  from oracle import frt_layout, numpy_oracle
+  stencil = core.from_file(soda_path(name), tile_size=tile, iterate=iterate)
+  inputs = _inputs(stencil, extent, seed=11)
+  layout = stream.WireLayout(stencil, extent)
+  assert layout.tiles == 1
+  in_banks = frt_layout.scatter(layout, inputs)
+  prog = stream.StreamProgram(stencil, dense=True)
+  runs = {}
+  try:
+    assert not any(t.startswith('wire_') for t in prog.specs)
+    for mode in ('bands', 'whole'):
+      monkeypatch.setenv('SODA_HIP_HOST_BANDS', '1' if mode == 'bands' else '0')
+      monkeypatch.setenv('SODA_HIP_HOST_CHUNK_KB', '16')
+      monkeypatch.setenv('SODA_HIP_HOST_TRACE', '1')
+      out_banks = frt_layout.alloc(layout, stencil.output_names)
+      capfd.readouterr()
+      prog.run_banked_host(out_banks, in_banks, layout.cycle_count)
+      said = capfd.readouterr().err
+      assert prog.last_mode == 'dense'
+      # (the library's own account of the call, soda_host.cpp run_banded)
+      assert (' bands of ' in said) == (mode == 'bands'), said
+      got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+             for o, t in zip(stencil.output_names, stencil.output_types)}
+      frt_layout.gather(layout, out_banks, got)
+      runs[mode] = got
+  finally:
+    prog.close()
+  want = numpy_oracle.run(stencil, inputs) if iterate is None or iterate <= 2 \
+      else None
+  if want is None:
+    from oracle import c_oracle
+    want = c_oracle.COracle(stencil).run(inputs)
+  for o in stencil.output_names:
+    lo, hi = stencil.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert runs['bands'][o][idx].any()
+    assert np.array_equal(runs['bands'][o][idx], want[o][idx]), o
+    assert np.array_equal(runs['whole'][o], runs['bands'][o]), o
+
+
 @pytest.mark.gpu
 def test_wire_banks_at_any_address(built):
   """The bank copy kernels move 16 bytes per bank per thread when every bank
