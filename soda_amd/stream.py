@@ -101,14 +101,13 @@ def emit_late(stencil: core.Stencil) -> Optional[core.Stencil]:
   so its new position is inside the tile too.
 
   Iterated programs feed every output back as an input: each iteration then
-  moves the field by c, `iterate` x c in all -- which is the stencil offset of
-  the iterated program only while one tensor circulates (the largest linear
-  offset of a Minkowski sum is the sum of the largest offsets); with several
-  the inputs of the next iteration would sit at different displacements, so
-  those keep the copy pass."""
+  moves the field by c, `iterate` x c in all -- which must be the stencil offset
+  of the iterated program (it is while one tensor circulates: the largest
+  linear offset of a Minkowski sum is the sum of the largest offsets) and must
+  be the SAME c for every circulating tensor, or the inputs of the next
+  iteration would sit at different displacements; programs where it is not
+  keep the copy pass."""
   st = stencil
-  if st.iterate > 1 and (len(st.input_names) != 1 or len(st.output_names) != 1):
-    return None
   tile = st.tile_size
   total = stencil_offsets(st)
   late: Dict[str, tuple] = {}
@@ -118,6 +117,8 @@ def emit_late(stencil: core.Stencil) -> Optional[core.Stencil]:
     if util.serialize(c, tile) * st.iterate != total[s.name]:
       return None
     late[s.name] = tuple(c)
+  if st.iterate > 1 and len(set(late.values())) != 1:
+    return None
 
   def moved(node):
     # a later statement that reads an output reads it where it now lives

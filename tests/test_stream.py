@@ -144,6 +144,7 @@ def test_wire_chain_as_dense_view(name, extent):
     ('heat3d.soda', (70, 40, 7), None), ('sobel2d.soda', (32, 8), None),
     ('denoise2d.soda', (32, 14), None),             # two inputs, delayed
     ('coupled2d.soda', (32, 11), 1),                # two outputs, own offsets
+    ('coupled2d.soda', (32, 14), None),             # both circulate, same (0, 1)
 ])
 def test_outputs_born_at_their_wire_positions(name, extent, iterate):
   """`emit_late`: the program with every output's store index moved by the
@@ -222,10 +223,18 @@ def test_outputs_born_at_their_wire_positions(name, extent, iterate):
     assert name == 'never', 'every case here has a dense view'
 
 
-def test_several_circulating_tensors_keep_the_copy_pass():
-  st = core.from_file(soda_path('coupled2d.soda'))
-  assert st.iterate > 1 and len(st.output_names) == 2
+def test_circulating_tensors_that_move_apart_keep_the_copy_pass():
+  """Two tensors fed back with different late vectors: after one iteration
+  the next one's inputs would sit at different displacements."""
+  st = core.from_text(
+      'kernel: k\nburst width: 64\nunroll factor: 2\niterate: 2\n'
+      'input float: a(32, *)\ninput float: b(32, *)\n'
+      'output float: a2(0, 0) = a(0, 1) + b(0, 0)\n'
+      'output float: b2(0, 0) = b(1, 0) + a(0, 0)\n')
   assert stream.emit_late(st) is None
+  same = core.from_file(soda_path('coupled2d.soda'))
+  assert same.iterate > 1 and len(same.output_names) == 2
+  assert stream.emit_late(same) is not None
 
 
 @pytest.mark.parametrize('name,extent', [('denoise2d.soda', (32, 14)),
