@@ -308,6 +308,25 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
 }
 
 // ---- the ring of pinned staging slots -------------------------------------------
+// Is [ptr, ptr + bytes) host memory the DMA engine can address (hipHostMalloc,
+// hipHostRegister / soda_hip_host_register)?  Pageable memory answers
+// "unregistered" or an error, depending on the runtime.
+bool host_pinned(const void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return false;
+  const char* ends[2] = {static_cast<const char*>(ptr),
+                         static_cast<const char*>(ptr) + bytes - 1};
+  for (const char* q : ends) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (at.type != hipMemoryTypeHost) return false;
+  }
+  return true;
+}
+
 int HostRing::wait(int slot) {
   if (busy[slot]) {
     HIP_TRY(hipEventSynchronize(ev[slot]));
@@ -401,12 +420,18 @@ struct HostCall {
   int32_t zero[SODA_HIP_MAX_DIM] = {0, 0, 0, 0};
   std::vector<const void*> in_ptrs;     // device: inputs, then params
   int in_turn = 0;
+  // Tensors the DMA engine can reach where they are: dense arrays in pinned
+  // (hipHostMalloc'ed / registered) memory.  Their rows are neither packed nor
+  // unpacked and use no staging slot; an output needs its box to hold whole
+  // rows (or, in 2-D, a column range of them: one strided copy).
+  std::vector<char> in_direct, out_direct;
 
   const int32_t* lo(int o) const { return valid_lo ? valid_lo + o * dim : zero; }
   const int32_t* hi(int o) const { return valid_hi ? valid_hi + o * dim : extent; }
 
-  // is the slot the next send() packs into free (its last DMA done)?
-  bool can_send() {
+  // is the slot the next send() of input i packs into free (its last DMA done)?
+  bool can_send(int i) {
+    if (in_direct[i]) return true;
     const int sl = in_turn % slots;
     if (!p->ring_in.busy[sl]) return true;
     if (hipEventQuery(p->ring_in.ev[sl]) == hipSuccess) {
@@ -420,6 +445,14 @@ struct HostCall {
   // rows [a, b) of input i: packed into a pinned slot, sent on `stream`
   int send(int i, int64_t a, int64_t b, hipStream_t stream) {
     const int elem = p->plan.elem_size[i];
+    if (in_direct[i]) {
+      const size_t off = (size_t)a * plane * elem;
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(p->host_in[i].ptr) + off,
+                             static_cast<const char*>(inputs[i].ptr) + off,
+                             (size_t)(b - a) * plane * elem,
+                             hipMemcpyHostToDevice, stream));
+      return SODA_HIP_OK;
+    }
     const int sl = in_turn++ % slots;
     if (int rc = p->ring_in.wait(sl)) return rc;
     char* slot = p->ring_in.base + (size_t)sl * p->ring_in.slot_bytes;
@@ -447,11 +480,25 @@ struct HostCall {
             int sl, hipStream_t stream) {
     const int elem = p->plan.elem_size[p->plan.num_inputs + o];
     char* slot = p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes;
-    HIP_TRY(hipMemcpyAsync(slot,
-                           static_cast<const char*>(dev) +
-                               (size_t)(a - dev_row0) * plane * elem,
-                           (size_t)(b - a) * plane * elem,
-                           hipMemcpyDeviceToHost, stream));
+    const char* src = static_cast<const char*>(dev) +
+                      (size_t)(a - dev_row0) * plane * elem;
+    if (out_direct[o] == 1) {            // whole rows, straight home
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(outputs[o].ptr) +
+                                 (size_t)a * plane * elem,
+                             src, (size_t)(b - a) * plane * elem,
+                             hipMemcpyDeviceToHost, stream));
+    } else if (out_direct[o] == 2) {     // 2-D: columns [lo, hi) of the rows
+      const size_t pitch = (size_t)plane * elem, x0 = (size_t)lo(o)[0] * elem;
+      HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(outputs[o].ptr) +
+                                   (size_t)a * pitch + x0,
+                               pitch, src + x0, pitch,
+                               (size_t)(hi(o)[0] - lo(o)[0]) * elem,
+                               (size_t)(b - a), hipMemcpyDeviceToHost, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(slot, src, (size_t)(b - a) * plane * elem,
+                             hipMemcpyDeviceToHost, stream));
+    }
+    // (a direct chunk keeps its turn in the ring's bookkeeping, not its memory)
     HIP_TRY(hipEventRecord(p->ring_out.ev[sl], stream));
     p->ring_out.busy[sl] = true;
     return SODA_HIP_OK;
@@ -460,6 +507,7 @@ struct HostCall {
   // the valid box's part of rows [a, b) of output o: slot -> caller's array
   // (frt/host.py:357-375: nothing outside the box is touched)
   void deliver(int o, int64_t a, int64_t b, int sl) {
+    if (out_direct[o]) return;           // the DMA engine wrote it home
     const int elem = p->plan.elem_size[p->plan.num_inputs + o];
     char* slot = p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes;
     int32_t l[SODA_HIP_MAX_DIM], h[SODA_HIP_MAX_DIM];
@@ -678,7 +726,8 @@ int run_banded(HostCall& c, int64_t band_rows, int64_t g_lo, int64_t g_hi) {
     }
     // 4. send the next rows of the next input, if their slot is free (gi
     //    counts (row group, input) units)
-    if (gi < groups * plan.num_inputs && c.can_send()) {
+    if (gi < groups * plan.num_inputs &&
+        c.can_send((int)(gi % plan.num_inputs))) {
       const int64_t g = gi / plan.num_inputs;
       const int i = (int)(gi % plan.num_inputs);
       const int64_t a = g * c.chunk_rows;
@@ -742,12 +791,17 @@ int64_t choose_bands(HostCall& c, int64_t g_lo, int64_t g_hi) {
   double compute_ns = 0;
   for (int i = 0; i < plan.num_passes; ++i) compute_ns += count[i] * pass_ns[i];
   double in_row = 0, out_row = 0;        // bytes per index of the last dimension
-  for (int i = 0; i < plan.num_inputs; ++i)
+  double in_packed = 0, out_packed = 0;  // ... of them through the host threads
+  for (int i = 0; i < plan.num_inputs; ++i) {
     in_row += (double)c.plane * plan.elem_size[i];
+    if (!c.in_direct[i]) in_packed += (double)c.plane * plan.elem_size[i];
+  }
   int64_t out_lo = c.rows, out_hi = 0;   // rows some valid box holds
   for (int o = 0; o < plan.num_outputs; ++o) {
     if (c.empty(o)) continue;
     out_row += (double)c.plane * plan.elem_size[plan.num_inputs + o];
+    if (!c.out_direct[o])
+      out_packed += (double)c.plane * plan.elem_size[plan.num_inputs + o];
     if (c.lo(o)[c.ax] < out_lo) out_lo = c.lo(o)[c.ax];
     if (c.hi(o)[c.ax] > out_hi) out_hi = c.hi(o)[c.ax];
   }
@@ -756,7 +810,7 @@ int64_t choose_bands(HostCall& c, int64_t g_lo, int64_t g_hi) {
   const double whole = c.rows * in_row / kAlone + compute_ns +
                        (out_hi - out_lo) * out_row / kAlone;
   const double host_floor =
-      (c.rows * in_row + (out_hi - out_lo) * out_row) / kHost;
+      (c.rows * in_packed + (out_hi - out_lo) * out_packed) / kHost;
   double best = whole * 0.9;
   int64_t best_rows = 0;
   for (int64_t per_band = 1; per_band * c.chunk_rows < c.rows; ++per_band) {
@@ -999,6 +1053,18 @@ int soda_hip_host_copy_box(void* strided, const int32_t* stride, void* dense,
   return SODA_HIP_OK;
 }
 
+int soda_hip_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(SODA_HIP_ERR_INVALID, "host_register: nothing");
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return SODA_HIP_OK;
+}
+
+int soda_hip_host_unregister(void* ptr) {
+  if (!ptr) return SODA_HIP_OK;
+  HIP_TRY(hipHostUnregister(ptr));
+  return SODA_HIP_OK;
+}
+
 int soda_hip_run_host_box(soda_hip_program_t* p,
                           const soda_hip_host_tensor_t* inputs,
                           const soda_hip_host_tensor_t* outputs,
@@ -1047,6 +1113,38 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
       HIP_TRY(hipStreamCreateWithFlags(&p->hstream[k], hipStreamNonBlocking));
   c.rows = c.extent[c.ax];
   c.plane = c.cells / c.rows;
+  // dense arrays in pinned memory go by DMA from / to where they are
+  // (SODA_HIP_HOST_DIRECT=0: everything through the staging slots)
+  c.in_direct.assign(plan.num_inputs, 0);
+  c.out_direct.assign(plan.num_outputs, 0);
+  const char* direct_env = getenv("SODA_HIP_HOST_DIRECT");
+  if (!direct_env || strcmp(direct_env, "0")) {
+    for (int i = 0; i < plan.num_inputs; ++i)
+      c.in_direct[i] =
+          is_dense(inputs[i], c.dim) &&
+          host_pinned(inputs[i].ptr, (size_t)c.cells * plan.elem_size[i]);
+    for (int o = 0; o < plan.num_outputs; ++o) {
+      const int elem = plan.elem_size[plan.num_inputs + o];
+      if (c.empty(o) || !is_dense(outputs[o], c.dim) ||
+          !host_pinned(outputs[o].ptr, (size_t)c.cells * elem))
+        continue;
+      bool whole_rows = true, whole_above_0 = true;
+      for (int d = 0; d < c.ax; ++d) {
+        const bool full = c.lo(o)[d] == 0 && c.hi(o)[d] == c.extent[d];
+        whole_rows = whole_rows && full;
+        if (d > 0) whole_above_0 = whole_above_0 && full;
+      }
+      if (whole_rows) c.out_direct[o] = 1;
+      else if (c.dim == 2 && whole_above_0) c.out_direct[o] = 2;
+    }
+  }
+  if (getenv("SODA_HIP_HOST_TRACE")) {
+    int ni = 0, no = 0;
+    for (char f : c.in_direct) ni += f != 0;
+    for (char f : c.out_direct) no += f != 0;
+    fprintf(stderr, "soda_hip_run_host_box: by DMA in place: %d of %d inputs, "
+            "%d of %d outputs\n", ni, plan.num_inputs, no, plan.num_outputs);
+  }
   int max_elem = 1;
   for (int t = 0; t < plan.num_inputs + plan.num_outputs; ++t)
     if (plan.elem_size[t] > max_elem) max_elem = plan.elem_size[t];

@@ -159,6 +159,7 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
 bool is_dense(const soda_hip_host_tensor_t& t, int dim);
 // the same for a dense array that starts at index `row0` of the last
 // dimension, on up to `threads` threads (0: the pool's; soda_host.cpp)
+bool host_pinned(const void* ptr, size_t bytes);
 void copy_rows(char* strided, const int32_t* stride, char* dense,
                const int32_t* extent, const int32_t* lo, const int32_t* hi,
                int dim, int elem, bool to_dense, int32_t row0, int threads);

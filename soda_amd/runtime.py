@@ -246,6 +246,8 @@ API = {
     'soda_hip_host_copy_box': (ctypes.c_int, [
         _vp, _pi32, _vp, _pi32, _pi32, _pi32, _i32, _i32, _i32, _i32, _i32
     ]),
+    'soda_hip_host_register': (ctypes.c_int, [_vp, ctypes.c_size_t]),
+    'soda_hip_host_unregister': (ctypes.c_int, [_vp]),
     'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),
     'soda_hip_program_set_debug_buffer': (ctypes.c_int, [_vp, _vp]),
     'soda_hip_program_calibrate': (ctypes.c_int, [_vp, _pi32, _i32, _vp]),
@@ -1387,3 +1389,34 @@ class Stream:
 def synchronize(stream: int = 0) -> None:
   check(library().soda_hip_stream_synchronize(ctypes.c_void_p(stream)),
         'stream_synchronize')
+
+
+class pinned:
+  """`with runtime.pinned(a, b, ...):` -- the numpy arrays' memory registered
+  with the GPU for the duration (soda_hip_host_register), so that Program.run
+  moves dense ones by DMA from / to where they are instead of through the
+  staging slots.  Registering costs about one copy of the array: worth it for
+  arrays that live across many calls."""
+
+  def __init__(self, *arrays):
+    for a in arrays:
+      if not a.flags.c_contiguous:
+        raise util.InputError('pinned: a view with gaps cannot be registered '
+                              'as one range; pass its base array')
+    self._arrays = [a for a in arrays if a.size]
+    self._done = []
+
+  def __enter__(self):
+    lib = library()
+    for a in self._arrays:
+      check(lib.soda_hip_host_register(ctypes.c_void_p(a.ctypes.data),
+                                       a.nbytes), 'host_register')
+      self._done.append(a)
+    return self
+
+  def __exit__(self, *exc):
+    lib = library()
+    for a in self._done:
+      lib.soda_hip_host_unregister(ctypes.c_void_p(a.ctypes.data))
+    self._done = []
+    return False

@@ -815,6 +815,98 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
       assert np.array_equal(got[o], want[o]), o
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('kb', [16, 4096])
+def test_host_entry_on_pinned_arrays(built, monkeypatch, capfd, kb):
+  """Dense caller arrays in pinned memory (runtime.pinned = soda_hip_host_
+  register) go by DMA from / to where they are, no staging slot, no worker
+  thread: whole rows for boxes that hold whole rows, one strided copy per chunk
+  for a 2-D box that holds a column range, the slots where neither applies
+  (3-D boxes cut in dimension 0 / 1; a strided output).  Same bits as the
+  pageable run, nothing outside the box touched, whole and in bands."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  monkeypatch.setenv('SODA_HIP_HOST_CHUNK_KB', str(kb))
+  cases = [
+      ('jacobi2d.soda', (512, 700), dict(iterate=7), (4,)),    # columns [7, 505)
+      ('blur.soda', (768, 400), {}, ()),                       # columns [0, 766)
+      ('heat3d.soda', (64, 48, 160), dict(iterate=3), (2,)),   # inputs only
+      ('jacobi2d.soda', (256, 900), dict(iterate=5, border='preserve'), (4,)),
+      ('coupled2d.soda', (256, 500), dict(iterate=4), (2,)),   # 2 in, 2 out
+  ]
+  rng = np.random.default_rng(12)
+  for name, extent, kw, fuse in cases:
+    st = core.from_file(soda_path(name), **kw)
+    shape = extent[::-1]
+    ins = {}
+    for n, t in zip(st.input_names, st.input_types):
+      dt = np.dtype(t.np_name)
+      ins[n] = (rng.random(shape).astype(dt) if dt.kind == 'f'
+                else rng.integers(0, 2000, shape).astype(dt))
+    runs = {}
+    with runtime.Program(st, lower.LowerOptions(fuse=fuse),
+                         extent=extent) as prog:
+      for how in ('pageable', 'pinned', 'pinned in bands', 'pinned whole',
+                  'pinned, slots'):
+        monkeypatch.delenv('SODA_HIP_HOST_BANDS', raising=False)
+        monkeypatch.delenv('SODA_HIP_HOST_DIRECT', raising=False)
+        if how == 'pinned in bands':
+          monkeypatch.setenv('SODA_HIP_HOST_BANDS', '1')
+        if how == 'pinned whole':
+          monkeypatch.setenv('SODA_HIP_HOST_BANDS', '0')
+        if how == 'pinned, slots':
+          monkeypatch.setenv('SODA_HIP_HOST_DIRECT', '0')
+        outs = {n: np.full(shape, 77, np.dtype(t.np_name))
+                for n, t in zip(st.output_names, st.output_types)}
+        monkeypatch.setenv('SODA_HIP_HOST_TRACE', '1')
+        capfd.readouterr()
+        if how == 'pageable':
+          prog.run(ins, outputs=outs)
+        else:
+          with runtime.pinned(*ins.values(), *outs.values()):
+            prog.run(ins, outputs=outs)
+        said = capfd.readouterr().err
+        monkeypatch.delenv('SODA_HIP_HOST_TRACE')
+        n_in, n_out = len(st.input_names), len(st.output_names)
+        direct = how.startswith('pinned') and how != 'pinned, slots'
+        want_out = 0 if not direct or name == 'heat3d.soda' else n_out
+        assert 'in place: %d of %d inputs, %d of %d outputs' % (
+            n_in if direct else 0, n_in, want_out, n_out) in said, (name, how,
+                                                                    said)
+        if how == 'pinned in bands' and kb == 16:    # (4 MiB: one chunk)
+          assert ' bands of ' in said, (name, said)
+        runs[how] = outs
+    for how, outs in runs.items():
+      for o in st.output_names:
+        assert np.array_equal(outs[o].view(np.uint8),
+                              runs['pageable'][o].view(np.uint8)), (name, o, how)
+    for o in st.output_names:        # (the pageable run itself: box vs rest)
+      if st.preserve_border:
+        continue
+      lo, hi = st.valid_box(extent, o)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      mask = np.ones(shape, bool)
+      mask[idx] = False
+      assert (runs['pinned'][o][mask] == 77).all(), (name, o)
+      assert (runs['pinned'][o][idx] != 77).any(), (name, o)
+
+
+def test_pinned_detection(built):
+  """What soda_hip_run_host_box takes for DMA-able host memory: registered
+  ranges, whole; not pageable memory, not a range that ends outside its
+  registration (the library then uses the slots, silently)."""
+  import ctypes
+  from soda_amd import runtime
+  lib = runtime.library()
+  a = np.zeros(1 << 20, np.float32)
+  assert lib.soda_hip_host_register(ctypes.c_void_p(a.ctypes.data), 0) != 0
+  with runtime.pinned(a):
+    pass
+  with pytest.raises(Exception):
+    with runtime.pinned(a[::2]):
+      pass
+
+
 @pytest.mark.parametrize('name,tile,extent,iterate', [
     ('blur.soda', None, (2000, 700), None),
     ('jacobi2d.soda', (256,), (256, 1500), 6),     # 6 x (0, 1) late, 12 ghost rows

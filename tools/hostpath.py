@@ -82,6 +82,28 @@ def measure(label, name, extent, iterate, fuse, reps=3, check=True):
       ts.append((time.perf_counter() - t0) * 1e3)
     res['fresh_ms'] = min(ts)
     res['fresh_ms_all'] = [round(t, 2) for t in ts]
+    # the same arrays registered with the GPU (runtime.pinned): DMA from / to
+    # where they are, no staging slots, no worker threads
+    t0 = time.perf_counter()
+    with runtime.pinned(*ins.values(), *outs.values()):
+      res['register_ms'] = (time.perf_counter() - t0) * 1e3
+      before = {n: a.copy() for n, a in outs.items()}
+      for a in outs.values():
+        a[...] = 0
+      ts = []
+      for _ in range(reps):
+        t0 = time.perf_counter()
+        prog.run(ins, outputs=outs)
+        ts.append((time.perf_counter() - t0) * 1e3)
+      res['pinned_ms'] = min(ts)
+      res['pinned_ms_all'] = [round(t, 2) for t in ts]
+      bad = 0
+      for n in st.output_names:
+        lo, hi = st.valid_box(extent, n)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+        bad += int((outs[n][idx].view(np.uint8) !=
+                    before[n][idx].view(np.uint8)).sum())
+      res['pinned_bytes_differing_from_the_pageable_run'] = bad
   cells = float(np.prod(extent))
   res['cells_iters_per_s_incl_pcie'] = cells * iterate / (res['reused_ms'] * 1e-3)
   res['GBs_moved_reused'] = (res['bytes_in'] + res['bytes_out']) / (
