@@ -398,8 +398,8 @@ int soda_hip_host_unregister(void* ptr);
  * worker threads live on the GPU's NUMA node (SODA_HIP_HOST_NUMA=0: wherever
  * the scheduler puts them).  A dense tensor in pinned memory (hipHostMalloc,
  * hipHostRegister, soda_hip_host_register) skips the slots and the threads:
- * its rows go by DMA from / to the caller's array (an output when its box
- * holds whole rows or, in 2-D, a column range of them; SODA_HIP_HOST_DIRECT=0:
+ * its rows go by DMA from / to the caller's array (an output whose box does
+ * not hold whole rows by one strided copy per chunk; SODA_HIP_HOST_DIRECT=0:
  * never).  Results are the same bits either way.
  * The pack / unpack step alone, exported
  * for callers that stage their own transfers and for tests without a GPU:

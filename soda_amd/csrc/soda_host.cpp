@@ -422,8 +422,9 @@ struct HostCall {
   int in_turn = 0;
   // Tensors the DMA engine can reach where they are: dense arrays in pinned
   // (hipHostMalloc'ed / registered) memory.  Their rows are neither packed nor
-  // unpacked and use no staging slot; an output needs its box to hold whole
-  // rows (or, in 2-D, a column range of them: one strided copy).
+  // unpacked and use no staging slot; an output whose box does not hold whole
+  // rows goes home by one strided copy per chunk (2-D: a column range of the
+  // rows; 3-D: the box's part of the planes, 15.7 -> 13.9 ms for C4).
   std::vector<char> in_direct, out_direct;
 
   const int32_t* lo(int o) const { return valid_lo ? valid_lo + o * dim : zero; }
@@ -494,6 +495,23 @@ struct HostCall {
                                pitch, src + x0, pitch,
                                (size_t)(hi(o)[0] - lo(o)[0]) * elem,
                                (size_t)(b - a), hipMemcpyDeviceToHost, stream));
+    } else if (out_direct[o] == 3) {     // 3-D: the box's part of the planes
+      const size_t pitch = (size_t)extent[0] * elem;
+      hipMemcpy3DParms q;
+      memset(&q, 0, sizeof q);
+      q.srcPtr = make_hipPitchedPtr(
+          const_cast<char*>(static_cast<const char*>(dev)), pitch, pitch,
+          (size_t)extent[1]);
+      q.srcPos = make_hipPos((size_t)lo(o)[0] * elem, (size_t)lo(o)[1],
+                             (size_t)(a - dev_row0));
+      q.dstPtr = make_hipPitchedPtr(outputs[o].ptr, pitch, pitch,
+                                    (size_t)extent[1]);
+      q.dstPos = make_hipPos((size_t)lo(o)[0] * elem, (size_t)lo(o)[1],
+                             (size_t)a);
+      q.extent = make_hipExtent((size_t)(hi(o)[0] - lo(o)[0]) * elem,
+                                (size_t)(hi(o)[1] - lo(o)[1]), (size_t)(b - a));
+      q.kind = hipMemcpyDeviceToHost;
+      HIP_TRY(hipMemcpy3DAsync(&q, stream));
     } else {
       HIP_TRY(hipMemcpyAsync(slot, src, (size_t)(b - a) * plane * elem,
                              hipMemcpyDeviceToHost, stream));
@@ -1136,6 +1154,7 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
       }
       if (whole_rows) c.out_direct[o] = 1;
       else if (c.dim == 2 && whole_above_0) c.out_direct[o] = 2;
+      else if (c.dim == 3) c.out_direct[o] = 3;
     }
   }
   if (getenv("SODA_HIP_HOST_TRACE")) {

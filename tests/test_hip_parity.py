@@ -821,16 +821,16 @@ def test_host_entry_on_pinned_arrays(built, monkeypatch, capfd, kb):
   """Dense caller arrays in pinned memory (runtime.pinned = soda_hip_host_
   register) go by DMA from / to where they are, no staging slot, no worker
   thread: whole rows for boxes that hold whole rows, one strided copy per chunk
-  for a 2-D box that holds a column range, the slots where neither applies
-  (3-D boxes cut in dimension 0 / 1; a strided output).  Same bits as the
-  pageable run, nothing outside the box touched, whole and in bands."""
+  for a 2-D box that holds a column range or a 3-D box cut in dimension 0 / 1.
+  Same bits as the pageable run, nothing outside the box touched, whole and
+  in bands."""
   from soda_amd import core, runtime
   from soda_amd.codegen.hip import lower
   monkeypatch.setenv('SODA_HIP_HOST_CHUNK_KB', str(kb))
   cases = [
       ('jacobi2d.soda', (512, 700), dict(iterate=7), (4,)),    # columns [7, 505)
       ('blur.soda', (768, 400), {}, ()),                       # columns [0, 766)
-      ('heat3d.soda', (64, 48, 160), dict(iterate=3), (2,)),   # inputs only
+      ('heat3d.soda', (64, 48, 160), dict(iterate=3), (2,)),   # a 3-D box
       ('jacobi2d.soda', (256, 900), dict(iterate=5, border='preserve'), (4,)),
       ('coupled2d.soda', (256, 500), dict(iterate=4), (2,)),   # 2 in, 2 out
   ]
@@ -869,7 +869,7 @@ def test_host_entry_on_pinned_arrays(built, monkeypatch, capfd, kb):
         monkeypatch.delenv('SODA_HIP_HOST_TRACE')
         n_in, n_out = len(st.input_names), len(st.output_names)
         direct = how.startswith('pinned') and how != 'pinned, slots'
-        want_out = 0 if not direct or name == 'heat3d.soda' else n_out
+        want_out = n_out if direct else 0
         assert 'in place: %d of %d inputs, %d of %d outputs' % (
             n_in if direct else 0, n_in, want_out, n_out) in said, (name, how,
                                                                     said)
