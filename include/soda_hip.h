@@ -378,10 +378,12 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           const int32_t* valid_hi);
 /* Pins [ptr, ptr + bytes) of the caller's memory (hipHostRegister) so that the
  * two entries above reach it by DMA where it is -- for hosts that keep their
- * arrays across calls and do not link HIP themselves (the reference host
- * allocates once with aligned_alloc, frt/host.py:165-178).  Registering costs
- * about as much as one copy of the range: once per array, not per call.
- * Unregister before freeing the memory. */
+ * arrays across calls and do not link HIP themselves.  `ptr` must start a
+ * page (INVALID otherwise): the reference host's buffers do
+ * (aligned_alloc(4096, ...), frt/host.py:165-178); ranges inside malloc's
+ * heap share pages with other objects and are not accepted.  Meant for
+ * memory that lives long: registering costs about as much as one copy of the
+ * range -- once per array, not per call.  Unregister before freeing. */
 int soda_hip_host_register(void* ptr, size_t bytes);
 int soda_hip_host_unregister(void* ptr);
 /* How the two entries above move data (soda_host.cpp): through pinned staging
@@ -396,11 +398,14 @@ int soda_hip_host_unregister(void* ptr);
  * (SODA_HIP_HOST_BANDS=0: never, =1: by a fixed rule; SODA_HIP_HOST_TRACE=1
  * prints the estimates and where the host thread's time went).  Slots and
  * worker threads live on the GPU's NUMA node (SODA_HIP_HOST_NUMA=0: wherever
- * the scheduler puts them).  A dense tensor in pinned memory (hipHostMalloc,
- * hipHostRegister, soda_hip_host_register) skips the slots and the threads:
- * its rows go by DMA from / to the caller's array (an output whose box does
- * not hold whole rows by one strided copy per chunk; SODA_HIP_HOST_DIRECT=0:
- * never).  Results are the same bits either way.
+ * the scheduler puts them).  A dense tensor inside a range pinned with
+ * soda_hip_host_register skips the slots and the threads: its rows go by DMA
+ * from / to the caller's array (an output whose box does not hold whole rows
+ * by one strided copy per chunk).  SODA_HIP_HOST_DIRECT=0: never;
+ * =attributes: also memory the HIP runtime reports as host-pinned
+ * (hipHostMalloc, a hipHostRegister of the caller's) -- at the caller's risk:
+ * a registration that is stale or not writable faults the GPU.  Results are
+ * the same bits either way.
  * The pack / unpack step alone, exported
  * for callers that stage their own transfers and for tests without a GPU:
  * copies box [lo, hi) between a strided host array (strides in elements) and

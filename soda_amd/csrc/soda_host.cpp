@@ -308,11 +308,37 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
 }
 
 // ---- the ring of pinned staging slots -------------------------------------------
-// Is [ptr, ptr + bytes) host memory the DMA engine can address (hipHostMalloc,
-// hipHostRegister / soda_hip_host_register)?  Pageable memory answers
-// "unregistered" or an error, depending on the runtime.
+// Ranges pinned through soda_hip_host_register, start -> bytes.
+struct Registered {
+  std::mutex mu;
+  std::map<uintptr_t, size_t> ranges;
+};
+Registered& registered() {
+  static Registered* r = new Registered;     // (leaked: alive at exit)
+  return *r;
+}
+
+// Is [ptr, ptr + bytes) host memory the DMA engine may be pointed at?  Yes for
+// what lies inside ONE range registered through soda_hip_host_register.  What
+// the runtime says about other memory (hipPointerGetAttributes: hipHostMalloc,
+// somebody's hipHostRegister) is only taken on request
+// (SODA_HIP_HOST_DIRECT=attributes): a registration the library did not make
+// may be stale, partial or not writable, and a DMA into such a page is a GPU
+// fault, not an error code.
 bool host_pinned(const void* ptr, size_t bytes) {
   if (!ptr || !bytes) return false;
+  {
+    Registered& r = registered();
+    std::lock_guard<std::mutex> hold(r.mu);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(ptr);
+    auto it = r.ranges.upper_bound(p);
+    if (it != r.ranges.begin()) {
+      --it;
+      if (p >= it->first && p + bytes <= it->first + it->second) return true;
+    }
+  }
+  const char* env = getenv("SODA_HIP_HOST_DIRECT");
+  if (!env || strcmp(env, "attributes")) return false;
   const char* ends[2] = {static_cast<const char*>(ptr),
                          static_cast<const char*>(ptr) + bytes - 1};
   for (const char* q : ends) {
@@ -1073,12 +1099,31 @@ int soda_hip_host_copy_box(void* strided, const int32_t* stride, void* dense,
 
 int soda_hip_host_register(void* ptr, size_t bytes) {
   if (!ptr || !bytes) return fail(SODA_HIP_ERR_INVALID, "host_register: nothing");
+  // Whole pages of the caller's own: a range that starts inside a heap page
+  // shares it with whatever malloc puts next to it, and registrations coming
+  // and going over such pages beside the runtime's own pinning of pageable
+  // copies ended in GPU memory faults (tools/experiments/r05_host_soak.py).
+  if (reinterpret_cast<uintptr_t>(ptr) & 4095)
+    return fail(SODA_HIP_ERR_INVALID,
+                "host_register: the range must start on a page boundary "
+                "(aligned_alloc(4096, ...) as the reference host allocates, "
+                "frt/host.py:165-178; mmap)");
   HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  Registered& r = registered();
+  std::lock_guard<std::mutex> hold(r.mu);
+  r.ranges[reinterpret_cast<uintptr_t>(ptr)] = bytes;
   return SODA_HIP_OK;
 }
 
 int soda_hip_host_unregister(void* ptr) {
   if (!ptr) return SODA_HIP_OK;
+  {
+    Registered& r = registered();
+    std::lock_guard<std::mutex> hold(r.mu);
+    if (!r.ranges.erase(reinterpret_cast<uintptr_t>(ptr)))
+      return fail(SODA_HIP_ERR_INVALID,
+                  "host_unregister: not a range soda_hip_host_register pinned");
+  }
   HIP_TRY(hipHostUnregister(ptr));
   return SODA_HIP_OK;
 }

@@ -1391,32 +1391,63 @@ def synchronize(stream: int = 0) -> None:
         'stream_synchronize')
 
 
-class pinned:
-  """`with runtime.pinned(a, b, ...):` -- the numpy arrays' memory registered
-  with the GPU for the duration (soda_hip_host_register), so that Program.run
-  moves dense ones by DMA from / to where they are instead of through the
-  staging slots.  Registering costs about one copy of the array: worth it for
-  arrays that live across many calls."""
+class PinnedBuffer:
+  """Page-aligned host memory of its own (an anonymous mmap), registered with
+  the GPU for its lifetime (soda_hip_host_register): dense arrays carved from
+  it travel by DMA from / to where they are when handed to Program.run, no
+  staging slots, no worker threads.  Meant to live long -- allocate once, run
+  many times, close() at the end -- like the buffers the reference host
+  allocates once with aligned_alloc(4096, ...) (ref frt/host.py:165-178).
 
-  def __init__(self, *arrays):
-    for a in arrays:
-      if not a.flags.c_contiguous:
-        raise util.InputError('pinned: a view with gaps cannot be registered '
-                              'as one range; pass its base array')
-    self._arrays = [a for a in arrays if a.size]
-    self._done = []
+  Why not register any numpy array: heap memory shares pages with other
+  objects and is recycled by malloc; registrations that come and go over such
+  pages next to the HIP runtime's own pinning of pageable copies ended in GPU
+  memory faults in a soak (tools/experiments/r05_host_soak.py), so the library
+  only registers ranges that start on a page boundary."""
+
+  def __init__(self, nbytes: int):
+    import mmap
+    self.nbytes = max(int(nbytes), 1)
+    self._map = mmap.mmap(-1, self.nbytes)
+    self._addr = ctypes.addressof(ctypes.c_char.from_buffer(self._map))
+    check(library().soda_hip_host_register(ctypes.c_void_p(self._addr),
+                                           self.nbytes), 'host_register')
+    self._open = True
+
+  def array(self, shape, dtype, offset: int = 0):
+    """A dense numpy array of `shape` at byte `offset` of the buffer (the
+    caller keeps arrays apart; offsets should be multiples of 4096)."""
+    import numpy as np
+    dtype = np.dtype(dtype)
+    count = 1
+    for n in shape:
+      count *= int(n)
+    if offset < 0 or offset + count * dtype.itemsize > self.nbytes:
+      raise util.InputError('PinnedBuffer: %d bytes at offset %d do not fit %d'
+                            % (count * dtype.itemsize, offset, self.nbytes))
+    return np.frombuffer(self._map, dtype, count, offset).reshape(shape)
+
+  def close(self) -> None:
+    if not self._open:
+      return
+    self._open = False
+    rc = library().soda_hip_host_unregister(ctypes.c_void_p(self._addr))
+    try:
+      self._map.close()
+    except BufferError:       # arrays still alive: the pages go with them
+      pass
+    if rc:
+      raise util.BackendError('host_unregister: %s' % last_error())
 
   def __enter__(self):
-    lib = library()
-    for a in self._arrays:
-      check(lib.soda_hip_host_register(ctypes.c_void_p(a.ctypes.data),
-                                       a.nbytes), 'host_register')
-      self._done.append(a)
     return self
 
   def __exit__(self, *exc):
-    lib = library()
-    for a in self._done:
-      lib.soda_hip_host_unregister(ctypes.c_void_p(a.ctypes.data))
-    self._done = []
+    self.close()
     return False
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -818,8 +818,9 @@ def test_wire_format_kernel_abi(built, name, in_decl, extent, out_decl, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize('kb', [16, 4096])
 def test_host_entry_on_pinned_arrays(built, monkeypatch, capfd, kb):
-  """Dense caller arrays in pinned memory (runtime.pinned = soda_hip_host_
-  register) go by DMA from / to where they are, no staging slot, no worker
+  """Dense caller arrays in pinned memory (runtime.PinnedBuffer: page-aligned
+  memory under soda_hip_host_register, allocated once for the whole test, as a
+  host would) go by DMA from / to where they are, no staging slot, no worker
   thread: whole rows for boxes that hold whole rows, one strided copy per chunk
   for a 2-D box that holds a column range or a 3-D box cut in dimension 0 / 1.
   Same bits as the pageable run, nothing outside the box touched, whole and
@@ -835,76 +836,96 @@ def test_host_entry_on_pinned_arrays(built, monkeypatch, capfd, kb):
       ('coupled2d.soda', (256, 500), dict(iterate=4), (2,)),   # 2 in, 2 out
   ]
   rng = np.random.default_rng(12)
-  for name, extent, kw, fuse in cases:
-    st = core.from_file(soda_path(name), **kw)
-    shape = extent[::-1]
-    ins = {}
-    for n, t in zip(st.input_names, st.input_types):
-      dt = np.dtype(t.np_name)
-      ins[n] = (rng.random(shape).astype(dt) if dt.kind == 'f'
-                else rng.integers(0, 2000, shape).astype(dt))
-    runs = {}
-    with runtime.Program(st, lower.LowerOptions(fuse=fuse),
-                         extent=extent) as prog:
-      for how in ('pageable', 'pinned', 'pinned in bands', 'pinned whole',
-                  'pinned, slots'):
-        monkeypatch.delenv('SODA_HIP_HOST_BANDS', raising=False)
-        monkeypatch.delenv('SODA_HIP_HOST_DIRECT', raising=False)
-        if how == 'pinned in bands':
-          monkeypatch.setenv('SODA_HIP_HOST_BANDS', '1')
-        if how == 'pinned whole':
-          monkeypatch.setenv('SODA_HIP_HOST_BANDS', '0')
-        if how == 'pinned, slots':
-          monkeypatch.setenv('SODA_HIP_HOST_DIRECT', '0')
+  room = 1 << 22            # per tensor, four tensors: the largest case fits
+  with runtime.PinnedBuffer(4 * room) as pinned:
+    for case in cases:
+      _pinned_case(case, pinned, room, rng, monkeypatch, capfd, kb)
+
+
+def _pinned_case(case, pinned, room, rng, monkeypatch, capfd, kb):
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  name, extent, kw, fuse = case
+  st = core.from_file(soda_path(name), **kw)
+  shape = extent[::-1]
+  ins = {}
+  for n, t in zip(st.input_names, st.input_types):
+    dt = np.dtype(t.np_name)
+    ins[n] = (rng.random(shape).astype(dt) if dt.kind == 'f'
+              else rng.integers(0, 2000, shape).astype(dt))
+  # the same values in the pinned buffer: tensor k at k * room
+  pin_in = {}
+  for k, n in enumerate(st.input_names):
+    pin_in[n] = pinned.array(shape, ins[n].dtype, k * room)
+    pin_in[n][...] = ins[n]
+  runs = {}
+  with runtime.Program(st, lower.LowerOptions(fuse=fuse),
+                       extent=extent) as prog:
+    for how in ('pageable', 'pinned', 'pinned in bands', 'pinned whole',
+                'pinned, slots'):
+      monkeypatch.delenv('SODA_HIP_HOST_BANDS', raising=False)
+      monkeypatch.delenv('SODA_HIP_HOST_DIRECT', raising=False)
+      if how == 'pinned in bands':
+        monkeypatch.setenv('SODA_HIP_HOST_BANDS', '1')
+      if how == 'pinned whole':
+        monkeypatch.setenv('SODA_HIP_HOST_BANDS', '0')
+      if how == 'pinned, slots':
+        monkeypatch.setenv('SODA_HIP_HOST_DIRECT', '0')
+      if how == 'pageable':
         outs = {n: np.full(shape, 77, np.dtype(t.np_name))
                 for n, t in zip(st.output_names, st.output_types)}
-        monkeypatch.setenv('SODA_HIP_HOST_TRACE', '1')
-        capfd.readouterr()
-        if how == 'pageable':
-          prog.run(ins, outputs=outs)
-        else:
-          with runtime.pinned(*ins.values(), *outs.values()):
-            prog.run(ins, outputs=outs)
-        said = capfd.readouterr().err
-        monkeypatch.delenv('SODA_HIP_HOST_TRACE')
-        n_in, n_out = len(st.input_names), len(st.output_names)
-        direct = how.startswith('pinned') and how != 'pinned, slots'
-        want_out = n_out if direct else 0
-        assert 'in place: %d of %d inputs, %d of %d outputs' % (
-            n_in if direct else 0, n_in, want_out, n_out) in said, (name, how,
-                                                                    said)
-        if how == 'pinned in bands' and kb == 16:    # (4 MiB: one chunk)
-          assert ' bands of ' in said, (name, said)
-        runs[how] = outs
-    for how, outs in runs.items():
-      for o in st.output_names:
-        assert np.array_equal(outs[o].view(np.uint8),
-                              runs['pageable'][o].view(np.uint8)), (name, o, how)
-    for o in st.output_names:        # (the pageable run itself: box vs rest)
-      if st.preserve_border:
-        continue
-      lo, hi = st.valid_box(extent, o)
-      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
-      mask = np.ones(shape, bool)
-      mask[idx] = False
-      assert (runs['pinned'][o][mask] == 77).all(), (name, o)
-      assert (runs['pinned'][o][idx] != 77).any(), (name, o)
+      else:
+        outs = {}
+        for k, (n, t) in enumerate(zip(st.output_names, st.output_types)):
+          outs[n] = pinned.array(shape, np.dtype(t.np_name),
+                                 (len(ins) + k) * room)
+          outs[n][...] = 77
+      monkeypatch.setenv('SODA_HIP_HOST_TRACE', '1')
+      capfd.readouterr()
+      prog.run(ins if how == 'pageable' else pin_in, outputs=outs)
+      said = capfd.readouterr().err
+      monkeypatch.delenv('SODA_HIP_HOST_TRACE')
+      n_in, n_out = len(st.input_names), len(st.output_names)
+      direct = how.startswith('pinned') and how != 'pinned, slots'
+      want_out = n_out if direct else 0
+      assert 'in place: %d of %d inputs, %d of %d outputs' % (
+          n_in if direct else 0, n_in, want_out, n_out) in said, (name, how,
+                                                                  said)
+      if how == 'pinned in bands' and kb == 16:    # (4 MiB: one chunk)
+        assert ' bands of ' in said, (name, said)
+      runs[how] = {n: a.copy() for n, a in outs.items()}
+  for how, outs in runs.items():
+    for o in st.output_names:
+      assert np.array_equal(outs[o].view(np.uint8),
+                            runs['pageable'][o].view(np.uint8)), (name, o, how)
+  for o in st.output_names:        # (the pageable run itself: box vs rest)
+    if st.preserve_border:
+      continue
+    lo, hi = st.valid_box(extent, o)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    mask = np.ones(shape, bool)
+    mask[idx] = False
+    assert (runs['pinned'][o][mask] == 77).all(), (name, o)
+    assert (runs['pinned'][o][idx] != 77).any(), (name, o)
 
 
-def test_pinned_detection(built):
-  """What soda_hip_run_host_box takes for DMA-able host memory: registered
-  ranges, whole; not pageable memory, not a range that ends outside its
-  registration (the library then uses the slots, silently)."""
+def test_what_may_be_registered(built):
+  """soda_hip_host_register takes whole pages of the caller's own, nothing that
+  starts inside a heap page; unregistering what it did not register is an
+  error, not a call into the runtime."""
   import ctypes
   from soda_amd import runtime
   lib = runtime.library()
-  a = np.zeros(1 << 20, np.float32)
-  assert lib.soda_hip_host_register(ctypes.c_void_p(a.ctypes.data), 0) != 0
-  with runtime.pinned(a):
-    pass
-  with pytest.raises(Exception):
-    with runtime.pinned(a[::2]):
-      pass
+  with runtime.PinnedBuffer(1 << 16) as buf:
+    a = buf.array((128, 64), np.float32, 4096)
+    assert a.ctypes.data % 4096 == 0 and a.flags.c_contiguous
+    inside = ctypes.c_void_p(a.ctypes.data + 64)
+    assert lib.soda_hip_host_register(inside, 4096) != 0
+    assert 'page boundary' in runtime.last_error()
+    assert lib.soda_hip_host_unregister(inside) != 0
+    assert lib.soda_hip_host_register(ctypes.c_void_p(a.ctypes.data), 0) != 0
+    with pytest.raises(Exception):
+      buf.array((1 << 20,), np.float32)
 
 
 @pytest.mark.parametrize('name,tile,extent,iterate', [

@@ -23,6 +23,10 @@ def main():
   ap.add_argument('--trials', type=int, default=150)
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--out', default=None)
+  ap.add_argument('--verbose', action='store_true',
+                  help='print every trial\'s draw before running it')
+  ap.add_argument('--dry', action='store_true',
+                  help='print every trial\'s draw, run nothing (no GPU needed)')
   args = ap.parse_args()
   import torch
   from soda_amd import core, runtime
@@ -43,7 +47,8 @@ def main():
          'int32': torch.int32, 'uint8': torch.uint8}
   bad = 0
   t0 = time.time()
-  progs = {}
+  # 2-D: <= 4800 x 3008 x 4 B x 4 tensors; room for padding
+  pinned = None if args.dry else runtime.PinnedBuffer(4 * (60 << 20))
   for trial in range(args.trials):
     path, dim, its, fuse = menu[int(rng.integers(len(menu)))]
     iterate = int(rng.choice(its))
@@ -78,8 +83,36 @@ def main():
                 for n, t in zip(st.output_names, st.output_types)}
     outs = {n: a[..., pad_out // 2:pad_out // 2 + shape[-1]]
             for n, a in outs_big.items()}
-    key = (path, iterate, extent[0]) + (extent[1:-1])
-    prog = runtime.Program(st, lower.LowerOptions(fuse=fuse), extent=extent)
+    prog = None if args.dry else runtime.Program(
+        st, lower.LowerOptions(fuse=fuse), extent=extent)
+    # the caller's arrays registered with the GPU or not: dense ones (no
+    # padding) then go by DMA where they are, padded ones through the slots
+    # tensors live in ONE page-aligned buffer registered for the whole soak
+    # (runtime.PinnedBuffer), or in numpy's own memory
+    pin = ['none', 'all', 'inputs', 'outputs'][int(rng.integers(0, 4))]
+    if pinned is not None:
+      at = 0
+      for group, names, which in ((big, st.input_names, ('all', 'inputs')),
+                                  (outs_big, st.output_names, ('all', 'outputs'))):
+        for n in names:
+          if pin in which:
+            home = pinned.array(group[n].shape, group[n].dtype, at)
+            home[...] = group[n]
+            group[n] = home
+            at += -(-home.nbytes // 4096) * 4096
+      ins = {n: big[n][..., pad_in // 2:pad_in // 2 + shape[-1]] for n in ins}
+      outs = {n: a[..., pad_out // 2:pad_out // 2 + shape[-1]]
+              for n, a in outs_big.items()}
+    if args.dry or args.verbose:
+      print(json.dumps({'trial': trial, 'program': os.path.basename(path),
+                        'extent': extent, 'iterate': iterate,
+                        'chunk_kb': os.environ['SODA_HIP_HOST_CHUNK_KB'],
+                        'bands': bands, 'pinned': pin,
+                        'pads': [pad_in, pad_out],
+                        'out_at': [hex(outs_big[n].ctypes.data)
+                                   for n in st.output_names]}), flush=True)
+    if args.dry:
+      continue
     try:
       prog.run(ins, outputs=outs)
       dev_in = [torch.from_numpy(np.ascontiguousarray(ins[n]).view(
@@ -104,10 +137,12 @@ def main():
           print(json.dumps({'trial': trial, 'program': os.path.basename(path),
                             'extent': extent, 'iterate': iterate,
                             'chunk_kb': os.environ['SODA_HIP_HOST_CHUNK_KB'],
-                            'bands': bands, 'wrong_bytes': wrong,
+                            'bands': bands, 'pinned': pin,
+                            'pads': [pad_in, pad_out], 'wrong_bytes': wrong,
                             'touched_outside': touched}), flush=True)
     finally:
-      prog.close()
+      if prog is not None:
+        prog.close()
     if (trial + 1) % 25 == 0:
       print('... %d trials, %d bad, %.0f s' % (trial + 1, bad, time.time() - t0),
             flush=True)

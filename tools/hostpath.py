@@ -82,19 +82,32 @@ def measure(label, name, extent, iterate, fuse, reps=3, check=True):
       ts.append((time.perf_counter() - t0) * 1e3)
     res['fresh_ms'] = min(ts)
     res['fresh_ms_all'] = [round(t, 2) for t in ts]
-    # the same arrays registered with the GPU (runtime.pinned): DMA from / to
-    # where they are, no staging slots, no worker threads
+    # the same values in page-aligned memory registered with the GPU
+    # (runtime.PinnedBuffer = soda_hip_host_register, as a host that keeps its
+    # arrays across calls would): DMA from / to where they are, no staging
+    # slots, no worker threads
+    def page(n):
+      return -(-n // 4096) * 4096
+    sizes = [page(a.nbytes) for a in list(ins.values()) + list(outs.values())]
     t0 = time.perf_counter()
-    with runtime.pinned(*ins.values(), *outs.values()):
-      res['register_ms'] = (time.perf_counter() - t0) * 1e3
+    with runtime.PinnedBuffer(sum(sizes)) as buf:
+      res['allocate_and_register_ms'] = (time.perf_counter() - t0) * 1e3
       before = {n: a.copy() for n, a in outs.items()}
-      for a in outs.values():
-        a[...] = 0
+      at, pin_in, pin_out = 0, {}, {}
+      for n, a in ins.items():
+        pin_in[n] = buf.array(a.shape, a.dtype, at)
+        pin_in[n][...] = a
+        at += page(a.nbytes)
+      for n, a in outs.items():
+        pin_out[n] = buf.array(a.shape, a.dtype, at)
+        pin_out[n][...] = 0
+        at += page(a.nbytes)
       ts = []
       for _ in range(reps):
         t0 = time.perf_counter()
-        prog.run(ins, outputs=outs)
+        prog.run(pin_in, outputs=pin_out)
         ts.append((time.perf_counter() - t0) * 1e3)
+      outs = pin_out
       res['pinned_ms'] = min(ts)
       res['pinned_ms_all'] = [round(t, 2) for t in ts]
       bad = 0
