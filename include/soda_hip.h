@@ -376,6 +376,16 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           const soda_hip_host_tensor_t* outputs,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi);
+/* The pack / unpack step of a tensor dealt over DRAM banks (the wire format's
+ * streams, below: element k in bank k % num_banks at index k / num_banks;
+ * reference docs/data-layout.md "Multi-Bank", frt/host.py:241-246,422-424):
+ * stream elements [first, first + count) <-> a dense run starting at `dense`;
+ * first and count multiples of num_banks.  What soda_hip_stream_run_host does
+ * with banked tensors on its way through the staging slots; exported for
+ * tests without a GPU.  threads as soda_hip_host_copy_box. */
+int soda_hip_host_weave_banks(void* const* banks, int32_t num_banks, void* dense,
+                              int64_t first, int64_t count, int32_t elem,
+                              int32_t to_dense, int32_t threads);
 /* Pins [ptr, ptr + bytes) of the caller's memory (hipHostRegister) so that the
  * two entries above reach it by DMA where it is -- for hosts that keep their
  * arrays across calls and do not link HIP themselves.  `ptr` must start a
@@ -650,11 +660,14 @@ int soda_hip_stream_run_device(soda_hip_stream_t* stream,
                                uint64_t coalesced_data_num, void* hip_stream);
 /* The same on host buffers sized as the reference host allocates them
  * (coalesced_data_num x elems_per_cycle / banks elements per bank): what
- * <app>_kernel receives under SODA_CPP_BINDING.  Synchronous.  Where every
- * tensor is on one bank, in place, and the stream is a dense array of rows,
- * the banks go through soda_hip_run_host_box on the n-D program (bands:
- * copy-in, kernels and copy-out overlapped; SODA_HIP_STREAM_NO_BANDS=1: whole
- * banks in, run, whole banks out, as for every other stream). */
+ * <app>_kernel receives under SODA_CPP_BINDING.  Synchronous.  Where the
+ * program stores its outputs late itself, no input is delayed and the stream
+ * is a dense array of rows, the banks go through the host-array entry on the
+ * n-D program (bands: copy-in, kernels and copy-out overlapped; a banked
+ * tensor is (de)interleaved by the host threads on its way through the
+ * staging slots, no copy kernel runs; SODA_HIP_STREAM_NO_BANDS=1: whole banks
+ * in, copy kernels, run, copy kernels, whole banks out, as for every other
+ * stream). */
 int soda_hip_stream_run_host(soda_hip_stream_t* stream, void* const* out_banks,
                              const void* const* in_banks,
                              uint64_t coalesced_data_num);

@@ -1558,11 +1558,12 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
   // n-D program, and the call is the host-array entry's (soda_host.cpp) --
   // copy-in, kernels and copy-out overlapped in bands along the rows.  The
   // elements of the partial last row stay as the caller left them (void tail).
+  // Banked tensors ride along: their (de)interleave is done by the host
+  // threads in the pack / unpack step instead of by copy kernels on the GPU.
   {
     bool in_place = !getenv("SODA_HIP_STREAM_NO_BANDS");
-    for (int i = 0; i < d.num_inputs; ++i)
-      in_place = in_place && d.banks[i] == 1 && d.shift[i] == 0;
-    for (int o = 0; o < d.num_outputs; ++o) in_place = in_place && !s->wire[o];
+    for (int t = 0; t < d.num_inputs + d.num_outputs; ++t)
+      in_place = in_place && d.shift[t] == 0;
     const uint64_t n64 = coalesced_data_num * (uint64_t)d.elems_per_cycle[0];
     int32_t ext[SODA_HIP_MAX_DIM];
     if (in_place && n64 >= 1 && n64 < (1ull << 31) &&
@@ -1575,18 +1576,29 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
       }
       std::vector<soda_hip_host_tensor_t> tin(d.num_inputs), tout(d.num_outputs);
       bool null_bank = false;
-      for (int i = 0; i < d.num_inputs; ++i) {
-        tin[i] = {const_cast<void*>(in_banks[i]), ext, stride, nullptr};
-        null_bank = null_bank || !in_banks[i];
+      int bank = 0;
+      for (int i = 0; i < d.num_inputs; bank += d.banks[i], ++i) {
+        for (int b = 0; b < d.banks[i]; ++b)
+          null_bank = null_bank || !in_banks[bank + b];
+        // one bank: the array itself; several: the list of them
+        tin[i] = {d.banks[i] == 1
+                      ? const_cast<void*>(in_banks[bank])
+                      : const_cast<void*>(static_cast<const void*>(in_banks + bank)),
+                  ext, stride, nullptr};
       }
-      for (int o = 0; o < d.num_outputs; ++o) {
-        tout[o] = {out_banks[o], ext, stride, nullptr};
-        null_bank = null_bank || !out_banks[o];
+      bank = 0;
+      for (int o = 0; o < d.num_outputs; bank += d.banks[d.num_inputs + o], ++o) {
+        for (int b = 0; b < d.banks[d.num_inputs + o]; ++b)
+          null_bank = null_bank || !out_banks[bank + b];
+        tout[o] = {d.banks[d.num_inputs + o] == 1
+                       ? out_banks[bank]
+                       : const_cast<void*>(static_cast<const void*>(out_banks + bank)),
+                   ext, stride, nullptr};
       }
       if (null_bank)
         return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL bank");
-      int rc = soda_hip_run_host_box(s->dense, tin.data(), tout.data(),
-                                     d.iterate, nullptr, nullptr);
+      int rc = run_host_call(s->dense, tin.data(), tout.data(), d.iterate,
+                             nullptr, nullptr, d.banks);
       if (rc == SODA_HIP_OK) {
         s->last_mode = 1;
         return rc;

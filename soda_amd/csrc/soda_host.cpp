@@ -307,6 +307,86 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
   copy_rows(strided, stride, dense, extent, lo, hi, dim, elem, to_dense, 0, 0);
 }
 
+// Stream elements [first, first + count) of a tensor dealt cyclically over
+// `nb` banks -- element k in bank k % nb at index k / nb (reference
+// docs/data-layout.md "Multi-Bank"; frt/host.py:241-246, 422-424) -- <-> a
+// dense run that starts at `dense`.  first and count are multiples of nb.
+// (the bank count as a template constant: the compiler turns the loops into
+// unpack / shuffle sequences; with a run-time count they stay scalar, 1-6 GB/s
+// a thread instead of 10-20)
+template <typename T, int NB>
+static void weave_fixed(T* const* banks, T* __restrict__ dense, int64_t j0,
+                        int64_t n, bool to_dense) {
+  T* __restrict__ bp[NB];
+  for (int b = 0; b < NB; ++b) bp[b] = banks[b] + j0;
+  if (to_dense) {
+    for (int64_t j = 0; j < n; ++j)
+      for (int b = 0; b < NB; ++b) dense[j * NB + b] = bp[b][j];
+  } else {
+    for (int64_t j = 0; j < n; ++j)
+      for (int b = 0; b < NB; ++b) bp[b][j] = dense[j * NB + b];
+  }
+}
+
+template <typename T>
+static void weave_run(T* const* banks, int nb, T* dense, int64_t j0, int64_t j1,
+                      int64_t jbase, bool to_dense) {
+  T* d0 = dense + (j0 - jbase) * nb;
+  switch (nb) {
+    case 1: weave_fixed<T, 1>(banks, d0, j0, j1 - j0, to_dense); return;
+    case 2: weave_fixed<T, 2>(banks, d0, j0, j1 - j0, to_dense); return;
+    case 3: weave_fixed<T, 3>(banks, d0, j0, j1 - j0, to_dense); return;
+    case 4: weave_fixed<T, 4>(banks, d0, j0, j1 - j0, to_dense); return;
+    case 8: weave_fixed<T, 8>(banks, d0, j0, j1 - j0, to_dense); return;
+    default: break;
+  }
+  if (to_dense) {
+    for (int64_t j = j0; j < j1; ++j) {
+      T* d = dense + (j - jbase) * nb;
+      for (int b = 0; b < nb; ++b) d[b] = banks[b][j];
+    }
+  } else {
+    for (int64_t j = j0; j < j1; ++j) {
+      const T* d = dense + (j - jbase) * nb;
+      for (int b = 0; b < nb; ++b) banks[b][j] = d[b];
+    }
+  }
+}
+
+void weave_banks(char* const* banks, int nb, char* dense, int64_t first,
+                 int64_t count, int elem, bool to_dense, int threads) {
+  const int64_t jbase = first / nb, groups = count / nb;
+  if (groups < 1) return;
+  // ~1 MiB of the dense side per task
+  int64_t per_task = (1 << 20) / ((int64_t)nb * elem);
+  if (per_task < 1) per_task = 1;
+  const int64_t tasks = (groups + per_task - 1) / per_task;
+  auto body = [&](size_t task) {
+    const int64_t j0 = jbase + (int64_t)task * per_task;
+    const int64_t j1 = j0 + per_task < jbase + groups ? j0 + per_task
+                                                        : jbase + groups;
+    switch (elem) {
+      case 1: weave_run((uint8_t* const*)banks, nb, (uint8_t*)dense, j0, j1, jbase, to_dense); break;
+      case 2: weave_run((uint16_t* const*)banks, nb, (uint16_t*)dense, j0, j1, jbase, to_dense); break;
+      case 4: weave_run((uint32_t* const*)banks, nb, (uint32_t*)dense, j0, j1, jbase, to_dense); break;
+      case 8: weave_run((uint64_t* const*)banks, nb, (uint64_t*)dense, j0, j1, jbase, to_dense); break;
+      default:
+        for (int64_t j = j0; j < j1; ++j)
+          for (int b = 0; b < nb; ++b) {
+            char* d = dense + ((j - jbase) * nb + b) * elem;
+            char* s = banks[b] + j * elem;
+            if (to_dense) memcpy(d, s, elem);
+            else memcpy(s, d, elem);
+          }
+    }
+  };
+  if (threads == 1 || tasks <= 1 || count * elem < (2 << 20)) {
+    for (int64_t t = 0; t < tasks; ++t) body((size_t)t);
+    return;
+  }
+  CopyPool::get().run((size_t)tasks, body);
+}
+
 // ---- the ring of pinned staging slots -------------------------------------------
 // Ranges pinned through soda_hip_host_register, start -> bytes.
 struct Registered {
@@ -452,6 +532,13 @@ struct HostCall {
   // rows goes home by one strided copy per chunk (2-D: a column range of the
   // rows; 3-D: the box's part of the planes, 15.7 -> 13.9 ms for C4).
   std::vector<char> in_direct, out_direct;
+  // Tensors dealt over DRAM banks (the wire format's streams on the host,
+  // soda_hip_stream_run_host): per tensor, inputs then outputs, the number of
+  // banks; where it is > 1 the tensor's `ptr` is the list of bank pointers and
+  // the interleave happens in the pack / unpack step the host pays anyway.
+  const int32_t* nbanks = nullptr;
+  int banks_in(int i) const { return nbanks ? nbanks[i] : 1; }
+  int banks_out(int o) const { return nbanks ? nbanks[p->plan.num_inputs + o] : 1; }
 
   const int32_t* lo(int o) const { return valid_lo ? valid_lo + o * dim : zero; }
   const int32_t* hi(int o) const { return valid_hi ? valid_hi + o * dim : extent; }
@@ -490,8 +577,12 @@ struct HostCall {
     }
     l[ax] = (int32_t)a;
     h[ax] = (int32_t)b;
-    copy_rows(static_cast<char*>(inputs[i].ptr), inputs[i].stride, slot, extent,
-              l, h, dim, elem, true, (int32_t)a, 0);
+    if (banks_in(i) > 1)
+      weave_banks(static_cast<char* const*>(inputs[i].ptr), banks_in(i), slot,
+                  a * plane, (b - a) * plane, elem, true, 0);
+    else
+      copy_rows(static_cast<char*>(inputs[i].ptr), inputs[i].stride, slot,
+                extent, l, h, dim, elem, true, (int32_t)a, 0);
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(p->host_in[i].ptr) +
                                (size_t)a * plane * elem,
                            slot, (size_t)(b - a) * plane * elem,
@@ -561,8 +652,12 @@ struct HostCall {
     }
     l[ax] = (int32_t)a;
     h[ax] = (int32_t)b;
-    copy_rows(static_cast<char*>(outputs[o].ptr), outputs[o].stride, slot,
-              extent, l, h, dim, elem, false, (int32_t)a, 0);
+    if (banks_out(o) > 1)       // (whole rows: checked where the call starts)
+      weave_banks(static_cast<char* const*>(outputs[o].ptr), banks_out(o), slot,
+                  a * plane, (b - a) * plane, elem, false, 0);
+    else
+      copy_rows(static_cast<char*>(outputs[o].ptr), outputs[o].stride, slot,
+                extent, l, h, dim, elem, false, (int32_t)a, 0);
   }
 
   bool empty(int o) const {
@@ -1128,16 +1223,42 @@ int soda_hip_host_unregister(void* ptr) {
   return SODA_HIP_OK;
 }
 
+int soda_hip_host_weave_banks(void* const* banks, int32_t num_banks, void* dense,
+                              int64_t first, int64_t count, int32_t elem,
+                              int32_t to_dense, int32_t threads) {
+  if (!banks || !dense || num_banks < 1 || elem < 1 || first < 0 || count < 0 ||
+      first % num_banks || count % num_banks || threads < 0)
+    return fail(SODA_HIP_ERR_INVALID, "host_weave_banks: bad argument");
+  for (int b = 0; b < num_banks; ++b)
+    if (!banks[b]) return fail(SODA_HIP_ERR_INVALID, "host_weave_banks: NULL bank");
+  weave_banks(reinterpret_cast<char* const*>(banks), num_banks,
+              static_cast<char*>(dense), first, count, elem, to_dense != 0,
+              threads);
+  return SODA_HIP_OK;
+}
+
 int soda_hip_run_host_box(soda_hip_program_t* p,
                           const soda_hip_host_tensor_t* inputs,
                           const soda_hip_host_tensor_t* outputs,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi) {
+  return run_host_call(p, inputs, outputs, iterate, valid_lo, valid_hi, nullptr);
+}
+
+}  // extern "C"
+
+namespace soda_detail {
+
+int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
+                  const soda_hip_host_tensor_t* outputs, int32_t iterate,
+                  const int32_t* valid_lo, const int32_t* valid_hi,
+                  const int32_t* nbanks) {
   if (!p || !inputs || !outputs)
     return fail(SODA_HIP_ERR_INVALID, "run_host: NULL argument");
   const soda_hip_plan_t& plan = p->plan;
   if (iterate < 1) return fail(SODA_HIP_ERR_INVALID, "cannot iterate < 1 times");
   HostCall c;
+  c.nbanks = nbanks;
   c.p = p;
   c.inputs = inputs;
   c.outputs = outputs;
@@ -1170,12 +1291,18 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
       if (c.lo(o)[d] < 0 || c.hi(o)[d] > c.extent[d])
         return fail(SODA_HIP_ERR_INVALID, "run_host: box outside the array");
   }
+  c.rows = c.extent[c.ax];
+  c.plane = c.cells / c.rows;
+  for (int t = 0; nbanks && t < plan.num_inputs + plan.num_outputs; ++t) {
+    if (nbanks[t] < 1 || c.plane % nbanks[t])
+      return fail(SODA_HIP_ERR_INVALID, "run_host: rows do not divide over the banks");
+    if (nbanks[t] > 1 && t >= plan.num_inputs && (valid_lo || valid_hi))
+      return fail(SODA_HIP_ERR_INVALID, "run_host: a banked output has no box");
+  }
   HIP_TRY(hipSetDevice(p->device));
   for (int k = 0; k < 3; ++k)
     if (!p->hstream[k])
       HIP_TRY(hipStreamCreateWithFlags(&p->hstream[k], hipStreamNonBlocking));
-  c.rows = c.extent[c.ax];
-  c.plane = c.cells / c.rows;
   // dense arrays in pinned memory go by DMA from / to where they are
   // (SODA_HIP_HOST_DIRECT=0: everything through the staging slots)
   c.in_direct.assign(plan.num_inputs, 0);
@@ -1184,11 +1311,11 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
   if (!direct_env || strcmp(direct_env, "0")) {
     for (int i = 0; i < plan.num_inputs; ++i)
       c.in_direct[i] =
-          is_dense(inputs[i], c.dim) &&
+          c.banks_in(i) == 1 && is_dense(inputs[i], c.dim) &&
           host_pinned(inputs[i].ptr, (size_t)c.cells * plan.elem_size[i]);
     for (int o = 0; o < plan.num_outputs; ++o) {
       const int elem = plan.elem_size[plan.num_inputs + o];
-      if (c.empty(o) || !is_dense(outputs[o], c.dim) ||
+      if (c.banks_out(o) > 1 || c.empty(o) || !is_dense(outputs[o], c.dim) ||
           !host_pinned(outputs[o].ptr, (size_t)c.cells * elem))
         continue;
       bool whole_rows = true, whole_above_0 = true;
@@ -1269,6 +1396,10 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
   }
   return run_whole(c);
 }
+
+}  // namespace soda_detail
+
+extern "C" {
 
 int soda_hip_run_host(soda_hip_program_t* p,
                       const soda_hip_host_tensor_t* inputs,

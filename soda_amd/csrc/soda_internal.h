@@ -159,6 +159,15 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
 bool is_dense(const soda_hip_host_tensor_t& t, int dim);
 // the same for a dense array that starts at index `row0` of the last
 // dimension, on up to `threads` threads (0: the pool's; soda_host.cpp)
+// soda_hip_run_host_box, with tensors that may be dealt over DRAM banks:
+// nbanks (NULL: none) holds, per tensor, inputs then outputs, the number of
+// banks; where it is > 1 the tensor's `ptr` is the list of its bank pointers.
+int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
+                  const soda_hip_host_tensor_t* outputs, int32_t iterate,
+                  const int32_t* valid_lo, const int32_t* valid_hi,
+                  const int32_t* nbanks);
+void weave_banks(char* const* banks, int nb, char* dense, int64_t first,
+                 int64_t count, int elem, bool to_dense, int threads);
 bool host_pinned(const void* ptr, size_t bytes);
 void copy_rows(char* strided, const int32_t* stride, char* dense,
                const int32_t* extent, const int32_t* lo, const int32_t* hi,

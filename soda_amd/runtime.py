@@ -246,6 +246,10 @@ API = {
     'soda_hip_host_copy_box': (ctypes.c_int, [
         _vp, _pi32, _vp, _pi32, _pi32, _pi32, _i32, _i32, _i32, _i32, _i32
     ]),
+    'soda_hip_host_weave_banks': (ctypes.c_int, [
+        ctypes.POINTER(ctypes.c_void_p), _i32, _vp, ctypes.c_int64,
+        ctypes.c_int64, _i32, _i32, _i32
+    ]),
     'soda_hip_host_register': (ctypes.c_int, [_vp, ctypes.c_size_t]),
     'soda_hip_host_unregister': (ctypes.c_int, [_vp]),
     'soda_hip_last_launches': (ctypes.c_int, [_vp, _pi32, _pi32]),

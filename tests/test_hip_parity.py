@@ -928,14 +928,18 @@ def test_what_may_be_registered(built):
       buf.array((1 << 20,), np.float32)
 
 
-@pytest.mark.parametrize('name,tile,extent,iterate', [
-    ('blur.soda', None, (2000, 700), None),
-    ('jacobi2d.soda', (256,), (256, 1500), 6),     # 6 x (0, 1) late, 12 ghost rows
-    ('heat3d.soda', (64, 32), (64, 32, 400), 2),
-    ('sobel2d.soda', (512,), (512, 900), None),
+@pytest.mark.parametrize('name,tile,extent,iterate,banks', [
+    ('blur.soda', None, (2000, 700), None, 1),
+    ('jacobi2d.soda', (256,), (256, 1500), 6, 1),  # 6 x (0, 1) late, 12 ghost rows
+    ('heat3d.soda', (64, 32), (64, 32, 400), 2, 1),
+    ('sobel2d.soda', (512,), (512, 900), None, 1),
+    # banked tensors: woven by the host threads in the pack / unpack step
+    ('blur.soda', (2048,), (2048, 600), None, 4),
+    ('jacobi2d.soda', (256,), (256, 1500), 6, 2),
+    ('heat3d.soda', (96, 32), (96, 32, 300), 2, 3),
 ])
 def test_wire_host_banks_in_bands(built, monkeypatch, capfd, name, tile, extent,
-                                  iterate):
+                                  iterate, banks):
   """<app>_kernel on host banks, every tensor in place on the dense view: the
   call goes through the host-array entry, here forced into bands of 16 KiB
   chunks (copy-in, kernels, copy-out overlapped; window runs with iterate x
@@ -943,15 +947,20 @@ def test_wire_host_banks_in_bands(built, monkeypatch, capfd, name, tile, extent,
   as the n-D oracle, and the same banks as one whole run."""
   from soda_amd import core, stream
   from oracle import frt_layout, numpy_oracle
-  stencil = core.from_file(soda_path(name), tile_size=tile, iterate=iterate)
+  import re
+  text = open(soda_path(name)).read()
+  if banks > 1:
+    text = re.sub(r'(input|output) dram [\d.]+',
+                  r'\1 dram ' + '.'.join(map(str, range(banks))), text)
+  stencil = core.from_text(text, tile_size=tile, iterate=iterate)
   inputs = _inputs(stencil, extent, seed=11)
   layout = stream.WireLayout(stencil, extent)
-  assert layout.tiles == 1
+  assert layout.tiles == 1 and max(layout.bank_count.values()) == banks
   in_banks = frt_layout.scatter(layout, inputs)
   prog = stream.StreamProgram(stencil, dense=True)
   runs = {}
   try:
-    assert not any(t.startswith('wire_') for t in prog.specs)
+    assert any(t.startswith('wire_') for t in prog.specs) == (banks > 1)
     for mode in ('bands', 'whole'):
       monkeypatch.setenv('SODA_HIP_HOST_BANDS', '1' if mode == 'bands' else '0')
       monkeypatch.setenv('SODA_HIP_HOST_CHUNK_KB', '16')

@@ -280,6 +280,50 @@ def test_wire_kernels_under_independent_hosts(built, tmp_path, main, soda):
         chunk_kb, run.stdout + run.stderr)
 
 
+@pytest.mark.parametrize('threads', [1, 0])
+def test_pack_and_unpack_of_banked_streams(built, threads):
+  """soda_hip_host_weave_banks: stream element k lives in bank k % nb at index
+  k / nb (reference docs/data-layout.md "Multi-Bank", frt/host.py:241-246,
+  422-424); a run of the stream <-> a dense staging run, both ways, on the
+  calling thread and on the pool, against numpy's own strided views; what lies
+  outside the run keeps its value."""
+  import ctypes
+  import numpy as np
+  from soda_amd import runtime
+  lib = runtime.library()
+  rng = np.random.default_rng(17)
+  for dt, nb, groups, first_g, count_g in (
+      (np.uint16, 4, 1 << 20, 0, 1 << 20),       # 8 MiB: the pool
+      (np.float32, 2, 700001, 100, 600000),
+      (np.uint8, 3, 50000, 7, 40000),
+      (np.float64, 8, 3000, 0, 3000),
+      (np.int16, 1, 4096, 16, 4000)):
+    stream = rng.integers(0, 250, groups * nb).astype(dt)
+    banks = [np.ascontiguousarray(stream[b::nb]) for b in range(nb)]
+    ptrs = (ctypes.c_void_p * nb)(*[b.ctypes.data for b in banks])
+    first, count = first_g * nb, count_g * nb
+    dense = np.full(count + 8, 251, dt)
+    assert lib.soda_hip_host_weave_banks(
+        ptrs, nb, ctypes.c_void_p(dense.ctypes.data), first, count,
+        dense.itemsize, 1, threads) == 0
+    assert np.array_equal(dense[:count], stream[first:first + count])
+    assert (dense[count:] == 251).all()
+    # and back into fresh banks
+    back = [np.full_like(b, 252) for b in banks]
+    bptrs = (ctypes.c_void_p * nb)(*[b.ctypes.data for b in back])
+    assert lib.soda_hip_host_weave_banks(
+        bptrs, nb, ctypes.c_void_p(dense.ctypes.data), first, count,
+        dense.itemsize, 0, threads) == 0
+    for b in range(nb):
+      want = np.full_like(banks[b], 252)
+      want[first_g:first_g + count_g] = banks[b][first_g:first_g + count_g]
+      assert np.array_equal(back[b], want), (dt, nb, b)
+  # runs that do not start or end on a whole group are refused
+  one = (ctypes.c_void_p * 2)(banks[0].ctypes.data, banks[0].ctypes.data)
+  assert lib.soda_hip_host_weave_banks(one, 2, ctypes.c_void_p(
+      dense.ctypes.data), 1, 4, 2, 1, 1) != 0
+
+
 def test_pack_and_unpack_from_several_caller_threads(built):
   """The worker pool serves one job at a time; callers from several threads
   take turns (CopyPool::run's `turn_` mutex).  Four Python threads pack big

@@ -15,5 +15,7 @@ for nb in "" 1; do
   python tools/streambench.py --host --steps 3 --soda $g/blur.soda --tile 16384 --extent 16384 16384 | grep host_banks >> $out
   python tools/streambench.py --host --steps 3 --soda $g/jacobi2d.soda --tile 8192 --iterate 100 --extent 8192 8192 | grep host_banks >> $out
   python tools/streambench.py --host --steps 3 --soda $g/heat3d.soda --tile 512 512 --iterate 50 --extent 512 512 512 | grep host_banks >> $out
+  python tools/streambench.py --host --steps 3 --soda $g/blur.soda --tile 16384 --banks 4 --extent 16384 16384 | grep host_banks >> $out
+  python tools/streambench.py --host --steps 3 --soda $g/jacobi2d.soda --tile 8192 --banks 2 --iterate 100 --extent 8192 8192 | grep host_banks >> $out
 done
 cat $out

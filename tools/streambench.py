@@ -97,6 +97,7 @@ def main():
       nbytes = sum(a.nbytes for v in list(hin.values()) + list(hout.values())
                    for a in v)
       print(json.dumps({'soda': os.path.basename(args.soda), 'mode': prog.last_mode,
+                        'banks': max(lay.bank_count.values()),
                         'host_banks_ms_per_call': round(min(ts), 3),
                         'bytes_moved': nbytes,
                         'GBs': nbytes / (min(ts) * 1e-3) / 1e9}))
