@@ -661,11 +661,11 @@ int soda_hip_stream_run_device(soda_hip_stream_t* stream,
 /* The same on host buffers sized as the reference host allocates them
  * (coalesced_data_num x elems_per_cycle / banks elements per bank): what
  * <app>_kernel receives under SODA_CPP_BINDING.  Synchronous.  Where the
- * program stores its outputs late itself, no input is delayed and the stream
- * is a dense array of rows, the banks go through the host-array entry on the
- * n-D program (bands: copy-in, kernels and copy-out overlapped; a banked
- * tensor is (de)interleaved by the host threads on its way through the
- * staging slots, no copy kernel runs; SODA_HIP_STREAM_NO_BANDS=1: whole banks
+ * program stores its outputs late itself and the stream is a dense array of
+ * rows, the banks go through the host-array entry on the n-D program (bands:
+ * copy-in, kernels and copy-out overlapped; a banked tensor is
+ * (de)interleaved, a delayed single-bank input un-delayed, by the host
+ * threads on its way through the staging slots, no copy kernel runs; SODA_HIP_STREAM_NO_BANDS=1: whole banks
  * in, copy kernels, run, copy kernels, whole banks out, as for every other
  * stream). */
 int soda_hip_stream_run_host(soda_hip_stream_t* stream, void* const* out_banks,

@@ -1562,8 +1562,10 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
   // threads in the pack / unpack step instead of by copy kernels on the GPU.
   {
     bool in_place = !getenv("SODA_HIP_STREAM_NO_BANDS");
+    // (a delayed input on ONE bank is un-delayed in the pack step as well)
     for (int t = 0; t < d.num_inputs + d.num_outputs; ++t)
-      in_place = in_place && d.shift[t] == 0;
+      in_place = in_place && (d.shift[t] == 0 ||
+                              (t < d.num_inputs && d.banks[t] == 1));
     const uint64_t n64 = coalesced_data_num * (uint64_t)d.elems_per_cycle[0];
     int32_t ext[SODA_HIP_MAX_DIM];
     if (in_place && n64 >= 1 && n64 < (1ull << 31) &&
@@ -1598,7 +1600,7 @@ int soda_hip_stream_run_host(soda_hip_stream_t* s, void* const* out_banks,
       if (null_bank)
         return fail(SODA_HIP_ERR_INVALID, "stream_run_host: NULL bank");
       int rc = run_host_call(s->dense, tin.data(), tout.data(), d.iterate,
-                             nullptr, nullptr, d.banks);
+                             nullptr, nullptr, d.banks, d.shift, (int64_t)n64);
       if (rc == SODA_HIP_OK) {
         s->last_mode = 1;
         return rc;

@@ -537,6 +537,12 @@ struct HostCall {
   // banks; where it is > 1 the tensor's `ptr` is the list of bank pointers and
   // the interleave happens in the pack / unpack step the host pays anyway.
   const int32_t* nbanks = nullptr;
+  // ... and single-bank inputs the generated host DELAYED (produce_offset,
+  // frt/host.py:241-246): dense element k is element k + lead[i] of the stream
+  // of stream_elems elements, zero beyond it -- undone in the pack step too.
+  const int32_t* lead = nullptr;
+  int64_t stream_elems = 0;
+  int64_t lead_in(int i) const { return lead ? lead[i] : 0; }
   int banks_in(int i) const { return nbanks ? nbanks[i] : 1; }
   int banks_out(int o) const { return nbanks ? nbanks[p->plan.num_inputs + o] : 1; }
 
@@ -577,7 +583,15 @@ struct HostCall {
     }
     l[ax] = (int32_t)a;
     h[ax] = (int32_t)b;
-    if (banks_in(i) > 1)
+    if (lead_in(i) > 0) {
+      const int64_t k0 = a * plane + lead_in(i), want = (b - a) * plane;
+      int64_t have = stream_elems - k0;
+      if (have > want) have = want;
+      if (have < 0) have = 0;
+      char* bank = static_cast<char*>(inputs[i].ptr);
+      weave_banks(&bank, 1, slot, k0, have, elem, true, 0);
+      memset(slot + (size_t)have * elem, 0, (size_t)(want - have) * elem);
+    } else if (banks_in(i) > 1)
       weave_banks(static_cast<char* const*>(inputs[i].ptr), banks_in(i), slot,
                   a * plane, (b - a) * plane, elem, true, 0);
     else
@@ -1242,7 +1256,8 @@ int soda_hip_run_host_box(soda_hip_program_t* p,
                           const soda_hip_host_tensor_t* outputs,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi) {
-  return run_host_call(p, inputs, outputs, iterate, valid_lo, valid_hi, nullptr);
+  return run_host_call(p, inputs, outputs, iterate, valid_lo, valid_hi, nullptr,
+                       nullptr, 0);
 }
 
 }  // extern "C"
@@ -1252,13 +1267,16 @@ namespace soda_detail {
 int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
                   const soda_hip_host_tensor_t* outputs, int32_t iterate,
                   const int32_t* valid_lo, const int32_t* valid_hi,
-                  const int32_t* nbanks) {
+                  const int32_t* nbanks, const int32_t* lead,
+                  int64_t stream_elems) {
   if (!p || !inputs || !outputs)
     return fail(SODA_HIP_ERR_INVALID, "run_host: NULL argument");
   const soda_hip_plan_t& plan = p->plan;
   if (iterate < 1) return fail(SODA_HIP_ERR_INVALID, "cannot iterate < 1 times");
   HostCall c;
   c.nbanks = nbanks;
+  c.lead = lead;
+  c.stream_elems = stream_elems;
   c.p = p;
   c.inputs = inputs;
   c.outputs = outputs;
@@ -1299,6 +1317,9 @@ int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
     if (nbanks[t] > 1 && t >= plan.num_inputs && (valid_lo || valid_hi))
       return fail(SODA_HIP_ERR_INVALID, "run_host: a banked output has no box");
   }
+  for (int i = 0; lead && i < plan.num_inputs; ++i)
+    if (lead[i] < 0 || (lead[i] > 0 && (c.banks_in(i) != 1 || stream_elems < 1)))
+      return fail(SODA_HIP_ERR_INVALID, "run_host: bad input delay");
   HIP_TRY(hipSetDevice(p->device));
   for (int k = 0; k < 3; ++k)
     if (!p->hstream[k])
@@ -1311,7 +1332,7 @@ int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
   if (!direct_env || strcmp(direct_env, "0")) {
     for (int i = 0; i < plan.num_inputs; ++i)
       c.in_direct[i] =
-          c.banks_in(i) == 1 && is_dense(inputs[i], c.dim) &&
+          c.banks_in(i) == 1 && c.lead_in(i) == 0 && is_dense(inputs[i], c.dim) &&
           host_pinned(inputs[i].ptr, (size_t)c.cells * plan.elem_size[i]);
     for (int o = 0; o < plan.num_outputs; ++o) {
       const int elem = plan.elem_size[plan.num_inputs + o];

@@ -159,13 +159,16 @@ void copy_box(char* strided, const int32_t* stride, char* dense,
 bool is_dense(const soda_hip_host_tensor_t& t, int dim);
 // the same for a dense array that starts at index `row0` of the last
 // dimension, on up to `threads` threads (0: the pool's; soda_host.cpp)
-// soda_hip_run_host_box, with tensors that may be dealt over DRAM banks:
-// nbanks (NULL: none) holds, per tensor, inputs then outputs, the number of
-// banks; where it is > 1 the tensor's `ptr` is the list of its bank pointers.
+// soda_hip_run_host_box, with tensors as the wire format's host streams hold
+// them: nbanks (NULL: none) holds, per tensor, inputs then outputs, the number
+// of DRAM banks -- where it is > 1 the tensor's `ptr` is the list of its bank
+// pointers; lead (NULL: none), per input, the elements the generated host
+// delayed a single-bank stream of stream_elems elements by.
 int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
                   const soda_hip_host_tensor_t* outputs, int32_t iterate,
                   const int32_t* valid_lo, const int32_t* valid_hi,
-                  const int32_t* nbanks);
+                  const int32_t* nbanks, const int32_t* lead,
+                  int64_t stream_elems);
 void weave_banks(char* const* banks, int nb, char* dense, int64_t first,
                  int64_t count, int elem, bool to_dense, int threads);
 bool host_pinned(const void* ptr, size_t bytes);

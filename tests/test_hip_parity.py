@@ -937,6 +937,9 @@ def test_what_may_be_registered(built):
     ('blur.soda', (2048,), (2048, 600), None, 4),
     ('jacobi2d.soda', (256,), (256, 1500), 6, 2),
     ('heat3d.soda', (96, 32), (96, 32, 300), 2, 3),
+    # two inputs, one delayed two tile rows by the host: un-delayed in the
+    # pack step (array exactly one tile wide, or the n-D oracle does not apply)
+    ('denoise2d.soda', (512,), (512, 900), None, 1),
 ])
 def test_wire_host_banks_in_bands(built, monkeypatch, capfd, name, tile, extent,
                                   iterate, banks):
