@@ -673,6 +673,13 @@ int soda_hip_stream_run_host(soda_hip_stream_t* stream, void* const* out_banks,
                              uint64_t coalesced_data_num);
 /* 1: the last run used the dense n-D form, 2: the linear form, 0: none yet */
 int soda_hip_stream_last_mode(soda_hip_stream_t* stream);
+/* soda_hip_stream_run_device takes the dense view only for tiles at least this
+ * wide in dimension 0 (default 256: narrower ones leave most of a marching
+ * strip idle and the linear form is faster on the GPU; 0: whenever there is a
+ * dense view).  soda_hip_stream_run_host always prefers the dense view: there
+ * the copies dominate, and the dense view lets them overlap in bands. */
+int soda_hip_stream_set_device_dense_min_tile(soda_hip_stream_t* stream,
+                                              int32_t min_tile0);
 
 /* -- device memory and timing helpers for hosts without their own -------- */
 int soda_hip_malloc(int32_t device, size_t bytes, void** ptr);

@@ -1367,6 +1367,12 @@ struct soda_hip_stream {
   std::vector<DeviceBuffer> host_banks;            // run_host staging
   bool dense_failed = false;
   int last_mode = 0;
+  // Device-resident banks narrower than this run the linear form even where
+  // the dense view exists: narrow tiles leave most of a 64-lane x V-wide
+  // marching strip idle (heat3d 32 x 32 tiles: 0.50 vs 0.79 ms).  Host banks
+  // take the dense view whenever there is one -- there the copies dominate and
+  // the dense view is what lets them overlap in bands.
+  int device_dense_min_tile0 = 256;
 };
 
 int soda_hip_stream_create(const soda_hip_stream_desc_t* desc,
@@ -1430,6 +1436,14 @@ int soda_hip_stream_destroy(soda_hip_stream_t* s) {
 }
 
 int soda_hip_stream_last_mode(soda_hip_stream_t* s) { return s ? s->last_mode : 0; }
+
+int soda_hip_stream_set_device_dense_min_tile(soda_hip_stream_t* s,
+                                              int32_t min_tile0) {
+  if (!s || min_tile0 < 0)
+    return fail(SODA_HIP_ERR_INVALID, "stream_set_device_dense_min_tile");
+  s->device_dense_min_tile0 = min_tile0;
+  return SODA_HIP_OK;
+}
 
 // Dense view: a stream of n elements is an array of extent (tile..., rows) iff
 // every tile starts on a row-block boundary -- a tile occupies
@@ -1515,7 +1529,7 @@ int soda_hip_stream_run_device(soda_hip_stream_t* s, void* const* out_banks,
   bool done = false;
   {
     int32_t ext[SODA_HIP_MAX_DIM];
-    if (dense_view(s, n, ext)) {
+    if (d.tile[0] >= s->device_dense_min_tile0 && dense_view(s, n, ext)) {
       int rc = soda_hip_run_device(s->dense, dout.data(), din.data(), ext,
                                    d.iterate, hip_stream);
       if (rc == SODA_HIP_OK) {

@@ -270,6 +270,7 @@ API = {
     'soda_hip_stream_run_host': (ctypes.c_int, [_vp, _pvp, _pvp,
                                                 ctypes.c_uint64]),
     'soda_hip_stream_last_mode': (ctypes.c_int, [_vp]),
+    'soda_hip_stream_set_device_dense_min_tile': (ctypes.c_int, [_vp, _i32]),
     'soda_hip_malloc': (ctypes.c_int, [_i32, ctypes.c_size_t, _pvp]),
     'soda_hip_free': (ctypes.c_int, [_i32, _vp]),
     'soda_hip_memcpy_h2d': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),

@@ -393,8 +393,11 @@ def stream_specs(stencil: core.Stencil, dense: Optional[bool] = None,
   # the original n-D program on the dense view of the stream; narrow tiles
   # leave most of a 64-lane x V-wide marching strip idle and the linear form
   # wins (heat3d 32 x 32 tiles: 0.50 vs 0.79 ms)
+  # (None: offered whenever the program is 2-D / 3-D; the library takes it for
+  # device-resident banks only from DENSE_MIN_TILE0 cells per tile row on, for
+  # host banks always -- soda_hip_stream_set_device_dense_min_tile)
   if dense is None:
-    dense = st.dim >= 2 and st.tile_size[0] >= StreamProgram.DENSE_MIN_TILE0
+    dense = st.dim >= 2
   if dense and st.dim >= 2:
     try:
       # (iterated programs: the depths the n-D entry offers; lower() clips
@@ -459,7 +462,8 @@ class StreamProgram:
   def __init__(self, stencil: core.Stencil, device: int = 0,
                dense: Optional[bool] = None, direct: bool = True):
     """`dense`: None = use the n-D marching kernels when the stream allows it
-    and the tile is wide enough to fill them, True = whenever the stream
+    and -- for device-resident banks -- the tile is wide enough to fill them
+    (host banks: whenever the stream allows it), True = whenever the stream
     allows it, False = always the linear form.  `direct`: see stream_specs."""
     self.stencil = stencil
     self.device = device
@@ -494,6 +498,10 @@ class StreamProgram:
         lib.soda_hip_stream_create(ctypes.byref(d), self._programs.get('dense'),
                                    lin, unw, wir, ctypes.byref(self._handle)),
         'stream object of `%s`' % stencil.app_name)
+    runtime.check(
+        lib.soda_hip_stream_set_device_dense_min_tile(
+            self._handle, 0 if dense else self.DENSE_MIN_TILE0),
+        'dense policy of `%s`' % stencil.app_name)
 
   @property
   def last_mode(self) -> Optional[str]:

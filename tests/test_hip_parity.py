@@ -995,6 +995,51 @@ def test_wire_host_banks_in_bands(built, monkeypatch, capfd, name, tile, extent,
 
 
 @pytest.mark.gpu
+def test_narrow_tiles_take_the_dense_view_on_host_banks_only(built):
+  """Tiles under 256 cells leave most of a marching strip idle, so device-
+  resident banks run the linear form there; host banks take the dense view
+  anyway -- the copies dominate and the dense view is what lets them overlap in
+  bands (soda_hip_stream_set_device_dense_min_tile).  Same cells either way."""
+  import torch
+  from soda_amd import core, stream
+  from oracle import frt_layout, numpy_oracle
+  stencil = core.from_file(soda_path('heat3d.soda'))         # 32 x 32 tiles
+  extent = (32, 32, 40)
+  inputs = _inputs(stencil, extent, seed=21)
+  layout = stream.WireLayout(stencil, extent)
+  in_banks = frt_layout.scatter(layout, inputs)
+  prog = stream.StreamProgram(stencil)                       # dense=None
+  try:
+    assert 'dense' in prog.specs
+    out_host = frt_layout.alloc(layout, stencil.output_names)
+    prog.run_banked_host(out_host, in_banks, layout.cycle_count)
+    assert prog.last_mode == 'dense'
+    dev_in = {n: [torch.from_numpy(b).cuda() for b in bs]
+              for n, bs in in_banks.items()}
+    dev_out = {n: [torch.zeros_like(torch.from_numpy(b)).cuda() for b in bs]
+               for n, bs in out_host.items()}
+    prog.run_banked_device({n: [t.data_ptr() for t in ts]
+                            for n, ts in dev_out.items()},
+                           {n: [t.data_ptr() for t in ts]
+                            for n, ts in dev_in.items()}, layout.cycle_count,
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert prog.last_mode == 'linear'
+    out_dev = {n: [t.cpu().numpy() for t in ts] for n, ts in dev_out.items()}
+  finally:
+    prog.close()
+  want = numpy_oracle.run(stencil, inputs)
+  for banks in (out_host, out_dev):
+    got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+           for o, t in zip(stencil.output_names, stencil.output_types)}
+    frt_layout.gather(layout, banks, got)
+    for o in stencil.output_names:
+      lo, hi = stencil.valid_box(extent, o)
+      idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+      assert got[o][idx].any() and np.array_equal(got[o][idx], want[o][idx])
+
+
+@pytest.mark.gpu
 def test_wire_banks_at_any_address(built):
   """The bank copy kernels move 16 bytes per bank per thread when every bank
   is 16-byte aligned, element by element otherwise: device banks that start 4
