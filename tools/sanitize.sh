@@ -13,8 +13,15 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 out=${1:-profiles/r05_sanitizers.txt}
-asan=$(gcc -print-file-name=libasan.so)
-tsan=$(gcc -print-file-name=libtsan.so)
+# (libstdc++ preloaded next to the sanitizer runtime: the runtime's __cxa_throw
+# interceptor looks its real function up when it starts, and in a Python that
+# loads libstdc++ later, with an extension module, finds none -- the first C++
+# exception in ANY extension then ends the process with "CHECK failed ...
+# real___cxa_throw != 0".  SciPy's HiGHS, which solves the produce-offset ILP,
+# throws one whenever its interior-point thread is interrupted: now and then.)
+stdcxx=$(gcc -print-file-name=libstdc++.so.6)
+asan="$(gcc -print-file-name=libasan.so) $stdcxx"
+tsan="$(gcc -print-file-name=libtsan.so) $stdcxx"
 lib=$PWD/soda_amd/_sanitize
 fail=0
 {
@@ -29,7 +36,7 @@ fail=0
   run() {   # label, preload, library, extra env..., -- pytest args
     local label=$1 preload=$2 which=$3; shift 3
     echo; echo "## $label"
-    env SODA_HIP_NO_TORCH=1 LD_PRELOAD=$preload SODA_HIP_LIBRARY=$which \
+    env SODA_HIP_NO_TORCH=1 LD_PRELOAD="$preload" SODA_HIP_LIBRARY=$which \
         ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
         UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
         TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 \
@@ -41,7 +48,7 @@ fail=0
     [ $rc -eq 0 ] || fail=1
   }
   run "libsoda_hip, ASan + UBSan: geometry, schedules, launch planning, group planning, pack / unpack" \
-      $asan $lib/libsoda_hip_asan.so \
+      "$asan" $lib/libsoda_hip_asan.so \
       python -m pytest -q -m "not gpu" -p no:cacheprovider \
       tests/test_codegen.py tests/test_group.py tests/test_host.py \
       tests/test_stream.py "tests/test_dist.py::test_exchange_interval_by_the_librarys_cost_choice" \
@@ -49,10 +56,10 @@ fail=0
   # (deselected: a wall-clock assertion -- plan_geometry of a 2M-row stream in
   # under 10 ms -- that an instrumented build on a busy box misses now and then)
   run "libsoda_hip, TSan: the worker pool of the host-array entry (pack / unpack on 8 threads)" \
-      $tsan $lib/libsoda_hip_tsan.so \
+      "$tsan" $lib/libsoda_hip_tsan.so \
       python -m pytest -q -m "not gpu" -p no:cacheprovider tests/test_host.py -k "pack_and_unpack"
   run "generated oracle nests, ASan + UBSan: corpus, golden vectors, fuzz seeds, independent nests" \
-      $asan $lib/libsoda_hip_asan.so SODA_ORACLE_SANITIZE=1 SODA_ORACLE_BUILD=/tmp/soda_oracle_asan_$$ \
+      "$asan" $lib/libsoda_hip_asan.so SODA_ORACLE_SANITIZE=1 SODA_ORACLE_BUILD=/tmp/soda_oracle_asan_$$ \
       python -m pytest -q -m "not gpu" -p no:cacheprovider \
       tests/test_oracle.py tests/test_fuzz.py tests/test_fuzz_nest.py
   rm -rf /tmp/soda_oracle_asan_$$
