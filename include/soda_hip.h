@@ -376,26 +376,6 @@ int soda_hip_run_host_box(soda_hip_program_t* program,
                           const soda_hip_host_tensor_t* outputs,
                           int32_t iterate, const int32_t* valid_lo,
                           const int32_t* valid_hi);
-/* The pack / unpack step of a tensor dealt over DRAM banks (the wire format's
- * streams, below: element k in bank k % num_banks at index k / num_banks;
- * reference docs/data-layout.md "Multi-Bank", frt/host.py:241-246,422-424):
- * stream elements [first, first + count) <-> a dense run starting at `dense`;
- * first and count multiples of num_banks.  What soda_hip_stream_run_host does
- * with banked tensors on its way through the staging slots; exported for
- * tests without a GPU.  threads as soda_hip_host_copy_box. */
-int soda_hip_host_weave_banks(void* const* banks, int32_t num_banks, void* dense,
-                              int64_t first, int64_t count, int32_t elem,
-                              int32_t to_dense, int32_t threads);
-/* Pins [ptr, ptr + bytes) of the caller's memory (hipHostRegister) so that the
- * two entries above reach it by DMA where it is -- for hosts that keep their
- * arrays across calls and do not link HIP themselves.  `ptr` must start a
- * page (INVALID otherwise): the reference host's buffers do
- * (aligned_alloc(4096, ...), frt/host.py:165-178); ranges inside malloc's
- * heap share pages with other objects and are not accepted.  Meant for
- * memory that lives long: registering costs about as much as one copy of the
- * range -- once per array, not per call.  Unregister before freeing. */
-int soda_hip_host_register(void* ptr, size_t bytes);
-int soda_hip_host_unregister(void* ptr);
 /* How the two entries above move data (soda_host.cpp): through pinned staging
  * slots the program owns, ~16 MiB chunks along the last dimension
  * (SODA_HIP_HOST_CHUNK_MB), packed / unpacked by a process-wide pool of worker
@@ -426,6 +406,26 @@ int soda_hip_host_copy_box(void* strided, const int32_t* stride, void* dense,
                            const int32_t* extent, const int32_t* lo,
                            const int32_t* hi, int32_t dim, int32_t elem,
                            int32_t to_dense, int32_t row0, int32_t threads);
+/* The pack / unpack step of a tensor dealt over DRAM banks (the wire format's
+ * streams, below: element k in bank k % num_banks at index k / num_banks;
+ * reference docs/data-layout.md "Multi-Bank", frt/host.py:241-246,422-424):
+ * stream elements [first, first + count) <-> a dense run starting at `dense`;
+ * first and count multiples of num_banks.  What soda_hip_stream_run_host does
+ * with banked tensors on its way through the staging slots; exported for
+ * tests without a GPU.  threads as soda_hip_host_copy_box. */
+int soda_hip_host_weave_banks(void* const* banks, int32_t num_banks, void* dense,
+                              int64_t first, int64_t count, int32_t elem,
+                              int32_t to_dense, int32_t threads);
+/* Pins [ptr, ptr + bytes) of the caller's memory (hipHostRegister) so that
+ * soda_hip_run_host / soda_hip_run_host_box reach it by DMA where it is -- for
+ * hosts that keep their arrays across calls and do not link HIP themselves.
+ * `ptr` must start a page (INVALID otherwise): the reference host's buffers
+ * do (aligned_alloc(4096, ...), frt/host.py:165-178); ranges inside malloc's
+ * heap share pages with other objects and are not accepted.  Meant for
+ * memory that lives long: registering costs about as much as one copy of the
+ * range -- once per array, not per call.  Unregister before freeing. */
+int soda_hip_host_register(void* ptr, size_t bytes);
+int soda_hip_host_unregister(void* ptr);
 
 /* Measures one launch of every pass on `extent` (stand-in arrays; two warming
  * rounds, then four rounds of `launches` back-to-back launches per pass inside
@@ -665,9 +665,9 @@ int soda_hip_stream_run_device(soda_hip_stream_t* stream,
  * rows, the banks go through the host-array entry on the n-D program (bands:
  * copy-in, kernels and copy-out overlapped; a banked tensor is
  * (de)interleaved, a delayed single-bank input un-delayed, by the host
- * threads on its way through the staging slots, no copy kernel runs; SODA_HIP_STREAM_NO_BANDS=1: whole banks
- * in, copy kernels, run, copy kernels, whole banks out, as for every other
- * stream). */
+ * threads on its way through the staging slots, no copy kernel runs;
+ * SODA_HIP_STREAM_NO_BANDS=1: whole banks in, copy kernels, run, copy kernels,
+ * whole banks out, as for every other stream). */
 int soda_hip_stream_run_host(soda_hip_stream_t* stream, void* const* out_banks,
                              const void* const* in_banks,
                              uint64_t coalesced_data_num);
