@@ -373,3 +373,88 @@ def test_delays_are_right_only_on_arrays_one_tile_wide():
     o = st.output_names[0]
     agree[extent[0]] = np.array_equal(got[o][idx], want[o][idx])
   assert agree == {32: True, 28: False}
+
+
+def test_late_programs_of_random_programs():
+  """emit_late over the random programs of tests/fuzz.py (several inputs,
+  outputs, locals, rich expressions, iterations): wherever it yields a
+  program, that program run plainly -- as the causal 1-D form and, where the
+  stream has one, on the dense view -- leaves every cell the host can hold the
+  kernel to where the contract wants it.  The numpy oracle is the kernel; the
+  GPU runs are in tests/test_hip_parity.py and tools/fuzz_scan.py wire."""
+  import fuzz
+  from oracle import frt_layout, numpy_oracle
+  from soda_amd import util
+  ran = dense_ran = 0
+  for seed in range(3000, 3120):
+    rng = np.random.default_rng(seed + 91000)
+    text, dim, _ = fuzz.program(seed, rich=bool(seed % 3 == 0))
+    if dim != 2:
+      continue
+    try:
+      st = core.from_text(text)
+      late = stream.emit_late(st)
+    except util.SodaError:
+      continue
+    if late is None:
+      continue
+    extent = (int(rng.integers(20, 33)) if seed % 4 else 32,
+              int(rng.integers(12, 30)))
+    boxes = [st.valid_box(extent, o) for o in st.output_names]
+    lo = [max(b[0][d] for b in boxes) for d in range(2)]
+    hi = [min(b[1][d] for b in boxes) for d in range(2)]
+    if not all(h > l for l, h in zip(lo, hi)):
+      continue
+    try:
+      lay = stream.WireLayout(st, extent)
+      ins = fuzz.inputs_for(st, extent, seed)
+      banks = frt_layout.scatter(lay, ins)
+      ref_banks = frt_layout.kernel_on_streams(lay, banks)
+    except (util.SodaError, ValueError, IndexError):
+      continue                 # (layouts the reference host itself cannot hold)
+    n = lay.cycle_count * lay.epc[st.input_names[0]]
+    streams = {}
+    for name in st.input_names:
+      s = np.zeros(n, banks[name][0].dtype)
+      s[:] = banks[name][0][:n]
+      po = st.produce_offsets()[name] if len(st.input_names) > 1 else 0
+      if po:
+        s = np.concatenate([s[po:], np.zeros(po, s.dtype)])
+      streams[name] = s
+    ref = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+           for o, t in zip(st.output_names, st.output_types)}
+    frt_layout.gather(lay, ref_banks, ref)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    # cells the two readings of the contract disagree on are nobody's
+    held = {o: np.ones(ref[o][idx].shape, bool) for o in ref}
+    other = frt_layout.kernel_on_dense_view(lay, banks)
+    if other is not None and len(st.output_names) > 1:
+      ref2 = {o: np.zeros_like(ref[o]) for o in ref}
+      frt_layout.gather(lay, other, ref2)
+      held = {o: ref[o][idx] == ref2[o][idx] for o in ref}
+
+    def check(out_streams, what):
+      out_banks = frt_layout.alloc(lay, st.output_names)
+      for o in st.output_names:
+        out_banks[o][0][:n] = out_streams[o][:n]
+      got = {o: np.zeros_like(ref[o]) for o in ref}
+      frt_layout.gather(lay, out_banks, got)
+      for o in st.output_names:
+        assert np.array_equal(got[o][idx][held[o]], ref[o][idx][held[o]],
+                              equal_nan=True), (seed, what, o)
+
+    check(numpy_oracle.run(stream.linearize(late), streams), 'linear')
+    ran += 1
+    block = st.tile_size[0]
+    if other is not None:
+      rows = n // block
+      out_nd = numpy_oracle.run(
+          late, {k: v[:rows * block].reshape((rows, block))
+                 for k, v in streams.items()})
+      flat = {}
+      for o in st.output_names:
+        flat[o] = np.zeros(n, out_nd[o].dtype)
+        flat[o][:rows * block] = out_nd[o].reshape(-1)
+      check(flat, 'dense')
+      dense_ran += 1
+  assert ran >= 25 and dense_ran >= 15, (ran, dense_ran)
