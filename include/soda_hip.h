@@ -49,6 +49,12 @@
 extern "C" {
 #endif
 
+/* Bumped when a struct that crosses the boundary changes layout (7: the plan
+ * carries the program's per-iteration reach).  Entry points added since, under
+ * the same number (no struct changed): soda_hip_host_register / _unregister,
+ * soda_hip_host_weave_banks, soda_hip_stream_set_device_dense_min_tile; and
+ * soda_hip_stream_create accepts wire[o] == NULL for an output on one bank
+ * that the program stores at its wire position itself. */
 #define SODA_HIP_ABI_VERSION 7
 #define SODA_HIP_MAX_DIM 4
 #define SODA_HIP_MAX_TENSORS 16
