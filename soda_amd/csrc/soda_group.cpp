@@ -830,6 +830,12 @@ int soda_hip_group_store(soda_hip_group_t* g,
         return rc;
     }
   }
+  // (rows that went home by DMA directly are still on their way)
+  for (auto& s : g->slabs) {
+    hipStream_t stream = nullptr;
+    if (int rc = host_stream(s->prog, &stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
   return SODA_HIP_OK;
 }
 

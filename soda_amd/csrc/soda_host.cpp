@@ -398,6 +398,12 @@ Registered& registered() {
   return *r;
 }
 
+// SODA_HIP_HOST_DIRECT=0: everything through the staging slots
+bool direct_allowed() {
+  const char* env = getenv("SODA_HIP_HOST_DIRECT");
+  return !env || strcmp(env, "0");
+}
+
 // Is [ptr, ptr + bytes) host memory the DMA engine may be pointed at?  Yes for
 // what lies inside ONE range registered through soda_hip_host_register.  What
 // the runtime says about other memory (hipPointerGetAttributes: hipHostMalloc,
@@ -509,6 +515,61 @@ int make_events(std::vector<hipEvent_t>* pool, size_t count) {
   return SODA_HIP_OK;
 }
 
+// How box [lo, hi) of a dense array in pinned memory can be filled by the DMA
+// engine: 1 = the box holds whole rows (plain copies), 2 = 2-D, a column range
+// of the rows (one strided copy per run of rows), 3 = 3-D, cut in dimension
+// 0 / 1 (one 3-D copy), 0 = not at all (dim > 3 with a cut box: the slots).
+int direct_mode(const int32_t* extent, const int32_t* lo, const int32_t* hi,
+                int dim) {
+  bool whole_rows = true, whole_above_0 = true;
+  for (int d = 0; d < dim - 1; ++d) {
+    const bool full = lo[d] == 0 && hi[d] == extent[d];
+    whole_rows = whole_rows && full;
+    if (d > 0) whole_above_0 = whole_above_0 && full;
+  }
+  if (whole_rows) return 1;
+  if (dim == 2 && whole_above_0) return 2;
+  return dim == 3 ? 3 : 0;
+}
+
+// Rows [a, b) of the box, from a device array that is dense from row
+// `dev_row0` on, straight into the caller's dense pinned array `host`.
+int dma_rows_home(int mode, void* host, const void* dev, int64_t dev_row0,
+                  const int32_t* extent, const int32_t* lo, const int32_t* hi,
+                  int dim, int elem, int64_t a, int64_t b, hipStream_t stream) {
+  int64_t plane = 1;
+  for (int d = 0; d < dim - 1; ++d) plane *= extent[d];
+  const char* src = static_cast<const char*>(dev) +
+                    (size_t)(a - dev_row0) * plane * elem;
+  if (mode == 1) {
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(host) + (size_t)a * plane * elem,
+                           src, (size_t)(b - a) * plane * elem,
+                           hipMemcpyDeviceToHost, stream));
+  } else if (mode == 2) {
+    const size_t pitch = (size_t)plane * elem, x0 = (size_t)lo[0] * elem;
+    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(host) + (size_t)a * pitch + x0,
+                             pitch, src + x0, pitch,
+                             (size_t)(hi[0] - lo[0]) * elem, (size_t)(b - a),
+                             hipMemcpyDeviceToHost, stream));
+  } else {
+    const size_t pitch = (size_t)extent[0] * elem;
+    hipMemcpy3DParms q;
+    memset(&q, 0, sizeof q);
+    q.srcPtr = make_hipPitchedPtr(
+        const_cast<char*>(static_cast<const char*>(dev)), pitch, pitch,
+        (size_t)extent[1]);
+    q.srcPos = make_hipPos((size_t)lo[0] * elem, (size_t)lo[1],
+                           (size_t)(a - dev_row0));
+    q.dstPtr = make_hipPitchedPtr(host, pitch, pitch, (size_t)extent[1]);
+    q.dstPos = make_hipPos((size_t)lo[0] * elem, (size_t)lo[1], (size_t)a);
+    q.extent = make_hipExtent((size_t)(hi[0] - lo[0]) * elem,
+                              (size_t)(hi[1] - lo[1]), (size_t)(b - a));
+    q.kind = hipMemcpyDeviceToHost;
+    HIP_TRY(hipMemcpy3DAsync(&q, stream));
+  }
+  return SODA_HIP_OK;
+}
+
 // What both ways of running share: the validated call, sizes, the rings.
 struct HostCall {
   soda_hip_program* p;
@@ -614,35 +675,10 @@ struct HostCall {
     char* slot = p->ring_out.base + (size_t)sl * p->ring_out.slot_bytes;
     const char* src = static_cast<const char*>(dev) +
                       (size_t)(a - dev_row0) * plane * elem;
-    if (out_direct[o] == 1) {            // whole rows, straight home
-      HIP_TRY(hipMemcpyAsync(static_cast<char*>(outputs[o].ptr) +
-                                 (size_t)a * plane * elem,
-                             src, (size_t)(b - a) * plane * elem,
-                             hipMemcpyDeviceToHost, stream));
-    } else if (out_direct[o] == 2) {     // 2-D: columns [lo, hi) of the rows
-      const size_t pitch = (size_t)plane * elem, x0 = (size_t)lo(o)[0] * elem;
-      HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(outputs[o].ptr) +
-                                   (size_t)a * pitch + x0,
-                               pitch, src + x0, pitch,
-                               (size_t)(hi(o)[0] - lo(o)[0]) * elem,
-                               (size_t)(b - a), hipMemcpyDeviceToHost, stream));
-    } else if (out_direct[o] == 3) {     // 3-D: the box's part of the planes
-      const size_t pitch = (size_t)extent[0] * elem;
-      hipMemcpy3DParms q;
-      memset(&q, 0, sizeof q);
-      q.srcPtr = make_hipPitchedPtr(
-          const_cast<char*>(static_cast<const char*>(dev)), pitch, pitch,
-          (size_t)extent[1]);
-      q.srcPos = make_hipPos((size_t)lo(o)[0] * elem, (size_t)lo(o)[1],
-                             (size_t)(a - dev_row0));
-      q.dstPtr = make_hipPitchedPtr(outputs[o].ptr, pitch, pitch,
-                                    (size_t)extent[1]);
-      q.dstPos = make_hipPos((size_t)lo(o)[0] * elem, (size_t)lo(o)[1],
-                             (size_t)a);
-      q.extent = make_hipExtent((size_t)(hi(o)[0] - lo(o)[0]) * elem,
-                                (size_t)(hi(o)[1] - lo(o)[1]), (size_t)(b - a));
-      q.kind = hipMemcpyDeviceToHost;
-      HIP_TRY(hipMemcpy3DAsync(&q, stream));
+    if (out_direct[o]) {
+      if (int rc = dma_rows_home(out_direct[o], outputs[o].ptr, dev, dev_row0,
+                                 extent, lo(o), hi(o), dim, elem, a, b, stream))
+        return rc;
     } else {
       HIP_TRY(hipMemcpyAsync(slot, src, (size_t)(b - a) * plane * elem,
                              hipMemcpyDeviceToHost, stream));
@@ -1093,6 +1129,19 @@ int send_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
   const int ax = dim - 1;
   int64_t plane = 1;
   for (int d = 0; d < ax; ++d) plane *= extent[d];
+  // a dense array in memory pinned with soda_hip_host_register: its rows go by
+  // DMA from where they are (one copy; N slabs on N GPUs: N links at once,
+  // no host thread in between)
+  if (direct_allowed() && is_dense(t, dim) &&
+      host_pinned(t.ptr, (size_t)plane * extent[ax] * elem)) {
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(dev) +
+                               (size_t)(a - dev_row0) * plane * elem,
+                           static_cast<const char*>(t.ptr) +
+                               (size_t)a * plane * elem,
+                           (size_t)(b - a) * plane * elem,
+                           hipMemcpyHostToDevice, stream));
+    return SODA_HIP_OK;
+  }
   const int64_t step = rows_per_chunk(plane * elem, b - a);
   const int slots = step < b - a ? HostRing::kMaxSlots : 1;
   if (int rc = ensure_ring(p, &p->ring_in, (size_t)step * plane * elem, slots))
@@ -1138,6 +1187,14 @@ int fetch_rows(soda_hip_program* p, const soda_hip_host_tensor_t& t,
   if (b <= a) return SODA_HIP_OK;
   int64_t plane = 1;
   for (int d = 0; d < ax; ++d) plane *= extent[d];
+  // (as send_rows; this one returns with the copy IN FLIGHT on `stream` -- the
+  // caller synchronises the streams it used)
+  if (direct_allowed() && is_dense(t, dim) &&
+      host_pinned(t.ptr, (size_t)plane * extent[ax] * elem)) {
+    if (const int mode = direct_mode(extent, lo, hi, dim))
+      return dma_rows_home(mode, t.ptr, dev, dev_row0, extent, lo, hi, dim, elem,
+                           a, b, stream);
+  }
   const int64_t step = rows_per_chunk(plane * elem, b - a);
   const int slots = step < b - a ? HostRing::kMaxSlots : 1;
   if (int rc = ensure_ring(p, &p->ring_out, (size_t)step * plane * elem, slots))
@@ -1328,8 +1385,7 @@ int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
   // (SODA_HIP_HOST_DIRECT=0: everything through the staging slots)
   c.in_direct.assign(plan.num_inputs, 0);
   c.out_direct.assign(plan.num_outputs, 0);
-  const char* direct_env = getenv("SODA_HIP_HOST_DIRECT");
-  if (!direct_env || strcmp(direct_env, "0")) {
+  if (direct_allowed()) {
     for (int i = 0; i < plan.num_inputs; ++i)
       c.in_direct[i] =
           c.banks_in(i) == 1 && c.lead_in(i) == 0 && is_dense(inputs[i], c.dim) &&
@@ -1339,15 +1395,7 @@ int run_host_call(soda_hip_program* p, const soda_hip_host_tensor_t* inputs,
       if (c.banks_out(o) > 1 || c.empty(o) || !is_dense(outputs[o], c.dim) ||
           !host_pinned(outputs[o].ptr, (size_t)c.cells * elem))
         continue;
-      bool whole_rows = true, whole_above_0 = true;
-      for (int d = 0; d < c.ax; ++d) {
-        const bool full = c.lo(o)[d] == 0 && c.hi(o)[d] == c.extent[d];
-        whole_rows = whole_rows && full;
-        if (d > 0) whole_above_0 = whole_above_0 && full;
-      }
-      if (whole_rows) c.out_direct[o] = 1;
-      else if (c.dim == 2 && whole_above_0) c.out_direct[o] = 2;
-      else if (c.dim == 3) c.out_direct[o] = 3;
+      c.out_direct[o] = (char)direct_mode(c.extent, c.lo(o), c.hi(o), c.dim);
     }
   }
   if (getenv("SODA_HIP_HOST_TRACE")) {

@@ -257,6 +257,54 @@ def test_virtual_slabs_equal_one_gpu(built, name, extent, iterate, fuse, slabs,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,extent,iterate,fuse,slabs', [
+    ('jacobi2d.soda', (512, 480), 9, (4,), 3),      # 2-D box: a column range
+    ('heat3d.soda', (64, 48, 96), 4, (2,), 4),      # 3-D box
+    ('blur.soda', (2048, 600), 1, (), 4),
+    ('coupled2d.soda', (256, 500), 4, (2,), 2),     # two tensors each way
+])
+def test_group_on_registered_arrays(built, name, extent, iterate, fuse, slabs):
+  """soda_hip_group_load / _store with the caller's arrays in memory pinned by
+  soda_hip_host_register (runtime.PinnedBuffer): every slab's rows go by DMA
+  from / to where they are -- N links at once on N GPUs, no host thread in
+  between -- and the result is the pageable run's, bit for bit, nothing outside
+  the valid box touched."""
+  from soda_amd import core, runtime
+  from soda_amd.codegen.hip import lower
+  stencil = core.from_file(soda_path(name), iterate=iterate)
+  inputs = _inputs(stencil, extent)
+  shape = extent[::-1]
+  room = 1 << 22
+  with runtime.Group(stencil, extent, [0] * slabs,
+                     lower.LowerOptions(fuse=fuse)) as group:
+    plain = group.run_host(inputs)
+    with runtime.PinnedBuffer(4 * room) as buf:
+      pin_in = {}
+      for k, n in enumerate(stencil.input_names):
+        pin_in[n] = buf.array(shape, inputs[n].dtype, k * room)
+        pin_in[n][...] = inputs[n]
+      outs = {}
+      for k, (n, t) in enumerate(zip(stencil.output_names,
+                                     stencil.output_types)):
+        outs[n] = buf.array(shape, np.dtype(t.np_name),
+                            (len(pin_in) + k) * room)
+        outs[n][...] = 77
+      group.load(pin_in)
+      group.run(iterate)
+      got = group.store(iterate, outputs=outs)
+      for o in stencil.output_names:
+        lo, hi = stencil.valid_box(extent, o, iterate)
+        idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+        assert got[o] is outs[o]
+        assert np.array_equal(got[o][idx].view(np.uint8),
+                              plain[o][idx].view(np.uint8)), o
+        mask = np.ones(shape, bool)
+        mask[idx] = False
+        assert (got[o][mask] == 77).all(), o
+        assert (got[o][idx] != 77).any(), o
+
+
+@pytest.mark.gpu
 def test_chained_group_runs_continue_from_the_result(built):
   """run(a) then run(b) == one run of a + b iterations: the second run opens
   with a halo exchange (its ghosts are stale), device-resident state."""
