@@ -995,6 +995,43 @@ def test_wire_host_banks_in_bands(built, monkeypatch, capfd, name, tile, extent,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['blur', 'jacobi2d_4tiles', 'heat3d_2x2tiles',
+                                 'denoise2d', 'blur_4banks', 'jacobi2d_2banks'])
+@pytest.mark.parametrize('dense', [True, False])
+def test_committed_wire_vectors_on_the_gpu(built, tag, dense):
+  """tests/golden/wire_*.npz: <app>_kernel on the COMMITTED input banks (host
+  banks, as the generated host passes them); what the host gathers from the
+  banks it leaves equals the committed outputs -- several tiles, 3-D tiles, a
+  delayed input, two and four banks, dense view and linear form."""
+  import importlib.util
+  from conftest import GOLDEN_DIR
+  from soda_amd import stream
+  from oracle import frt_layout
+  spec = importlib.util.spec_from_file_location(
+      'make_wire_golden', os.path.join(GOLDEN_DIR, 'make_wire_golden.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  case = [c for c in mod.CASES if c[0] == tag][0]
+  gold = np.load(os.path.join(GOLDEN_DIR, 'wire_%s.npz' % tag))
+  st = mod.program(case)
+  extent = tuple(int(x) for x in gold['extent'])
+  lay = stream.WireLayout(st, extent)
+  in_banks = {n: [np.ascontiguousarray(gold['inbank%d_%s' % (b, n)])
+                  for b in range(lay.bank_count[n])] for n in st.input_names}
+  out_banks = frt_layout.alloc(lay, st.output_names)
+  prog = stream.StreamProgram(st, dense=dense)
+  try:
+    prog.run_banked_host(out_banks, in_banks, int(gold['cycle_count']))
+  finally:
+    prog.close()
+  got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(st.output_names, st.output_types)}
+  frt_layout.gather(lay, out_banks, got)
+  for o in st.output_names:
+    assert np.array_equal(got[o], gold['out_' + o]), o
+
+
+@pytest.mark.gpu
 def test_narrow_tiles_take_the_dense_view_on_host_banks_only(built):
   """Tiles under 256 cells leave most of a marching strip idle, so device-
   resident banks run the linear form there; host banks take the dense view

@@ -458,3 +458,51 @@ def test_late_programs_of_random_programs():
       check(flat, 'dense')
       dense_ran += 1
   assert ran >= 25 and dense_ran >= 15, (ran, dense_ran)
+
+
+def _wire_cases():
+  import importlib.util
+  import os
+  from conftest import GOLDEN_DIR
+  spec = importlib.util.spec_from_file_location(
+      'make_wire_golden', os.path.join(GOLDEN_DIR, 'make_wire_golden.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+WIRE_TAGS = ['blur', 'jacobi2d_4tiles', 'heat3d_2x2tiles', 'denoise2d',
+             'blur_4banks', 'jacobi2d_2banks']
+
+
+@pytest.mark.parametrize('tag', WIRE_TAGS)
+def test_committed_wire_vectors(tag):
+  """tests/golden/wire_*.npz (tests/golden/make_wire_golden.py): the banks the
+  reference host's layout puts the caller's arrays in, the banks the kernel
+  contract leaves, what the host gathers -- as committed.  Today's layout code
+  and oracle reproduce every array bit for bit."""
+  import os
+  from oracle import frt_layout
+  mod = _wire_cases()
+  case = [c for c in mod.CASES if c[0] == tag][0]
+  from conftest import GOLDEN_DIR
+  gold = np.load(os.path.join(GOLDEN_DIR, 'wire_%s.npz' % tag))
+  st = mod.program(case)
+  extent = tuple(int(x) for x in gold['extent'])
+  assert extent == tuple(case[3])
+  lay = stream.WireLayout(st, extent)
+  assert lay.cycle_count == int(gold['cycle_count'])
+  ins = {n: gold['in_' + n] for n in st.input_names}
+  in_banks = frt_layout.scatter(lay, ins)
+  for n, bs in in_banks.items():
+    for b, a in enumerate(bs):
+      assert np.array_equal(a, gold['inbank%d_%s' % (b, n)]), (n, b)
+  out_banks = frt_layout.kernel_on_streams(lay, in_banks)
+  for n, bs in out_banks.items():
+    for b, a in enumerate(bs):
+      assert np.array_equal(a, gold['outbank%d_%s' % (b, n)]), (n, b)
+  got = {o: np.zeros(tuple(extent[::-1]), np.dtype(t.np_name))
+         for o, t in zip(st.output_names, st.output_types)}
+  frt_layout.gather(lay, out_banks, got)
+  for o in st.output_names:
+    assert got[o].any() and np.array_equal(got[o], gold['out_' + o]), o
