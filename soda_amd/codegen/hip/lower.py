@@ -313,6 +313,10 @@ def lower(stencil: core.Stencil, opts: Optional[LowerOptions] = None) -> Module:
     if len(derived.symbol_table) + len(derived.param_stmts) <= MAX_TENSORS \
         and same_boxes(derived):
       stencil = derived
+  # operations whose operand ranges the text proves: cheaper sequences with
+  # the same bits (exact.py; the program as written unless one is enabled)
+  from soda_amd.codegen.hip import exact
+  stencil = exact.specialize(stencil)
   mod = Module(stencil)
   if opts.strategy == 'lds':
     if stencil.preserve_border:

@@ -513,6 +513,10 @@ def c_expr(node: Node,
       if len(args) != 3:
         raise util.SemanticError('select() takes 3 arguments')
       return '((%s) ? (%s) : (%s))' % tuple(args)
+    if node.name.startswith('soda_'):
+      # a backend intrinsic (codegen/hip/exact.py): made by a lowering, never
+      # parsed -- FUNC_NAMES is what the grammar accepts
+      return '%s(%s)' % (node.name, ', '.join(args))
     if node.name in _C_FUNCS:
       f32, f64, fint = _C_FUNCS[node.name]
       if t is not None and t.is_float and t.width_in_bits <= 32:
