@@ -99,11 +99,12 @@ def variant() -> str:
   return v
 
 
-def helper_text(source_chunks) -> str:
-  """Device functions a module's kernels call (Module.source)."""
-  if variant() == 'off' or not any('soda_rsqrt_lb(' in c for c in source_chunks):
-    return ''
-  return VARIANTS[variant()]
+def helper_text(stencil: core.Stencil) -> str:
+  """Device functions the kernels of a module over `stencil` call
+  (Module.source): the variant `specialize` rewrote the program for -- noted
+  on the derived program itself, not read from the environment again."""
+  v = getattr(stencil, 'exact_rsqrt_variant', None)
+  return VARIANTS[v] if v else ''
 
 
 def _is_f32(node: ir.Node) -> bool:
@@ -181,6 +182,7 @@ def specialize(stencil: core.Stencil) -> core.Stencil:
   if not any(e.transform(_rewrite) is not e for e in exprs):
     return stencil
   derived = copy.deepcopy(stencil)
+  derived.exact_rsqrt_variant = variant()
   for s in derived.local_stmts + derived.output_stmts:
     s.expr = s.expr.transform(_rewrite)
     for l in s.let:
