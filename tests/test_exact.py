@@ -250,3 +250,90 @@ def test_denoise_kernels_keep_the_oracles_bits(name, extent):
       g, w = got[o][idx], want[o][idx]
       same = (g.view(np.int32) == w.view(np.int32)) | (np.isnan(g) & np.isnan(w))
       assert same.all(), (kind, o, int((~same).sum()))
+
+
+# --- random programs around the pattern --------------------------------------
+
+_CONSTS = ('1.0f', '0.00005f', '1.0e-25f', '3.0e20f', '0.5f + 0.25f', '7.0e-27f')
+
+
+def _random_program(seed: int):
+  """(text, extent): a program whose locals / output hold `1.0f / sqrt(c +
+  squares)` with c from 7e-27 (just above the 2^-90 the rewrite asks for) to
+  3e20, squares of differences of random taps, in 1 to 3 dimensions, the
+  quotient used at shifted positions, inside products and longer chains."""
+  rng = np.random.default_rng(1000 + seed)
+  dim = int(rng.integers(1, 4))
+  tile = {1: '', 2: '32, ', 3: '16, 8, '}[dim]
+
+  def tap(r=1):
+    return '(%s)' % ', '.join(str(int(rng.integers(-r, r + 1))) for _ in range(dim))
+
+  def square():
+    if rng.random() < 0.3:
+      t = 'u%s' % tap()
+      return '%s * %s' % (t, t)
+    d = '(u%s - u%s)' % (tap(), tap())
+    return '%s * %s' % (d, d)
+
+  def root(c):
+    terms = [c] + [square() for _ in range(int(rng.integers(1, 4)))]
+    return '1.0f / sqrt(%s)' % ' + '.join(terms)
+
+  c1, c2 = rng.choice(_CONSTS, 2)
+  zero = '(%s)' % ', '.join(['0'] * dim)
+  lines = ['kernel: rs%d' % seed, 'burst width: 64', 'unroll factor: 2',
+           'iterate: 1', 'input float: u(%s*)' % tile,
+           'local float: g%s = %s' % (zero, root(c1)),
+           'output float: o%s = u%s * g%s + g%s * u%s - %s * u%s / 3.0f' %
+           (zero, zero, tap(), tap(), tap(), root(c2), tap())]
+  extent = {1: (5000,), 2: (300, 200), 3: (70, 40, 30)}[dim]
+  return '\n'.join(lines) + '\n', extent
+
+
+RANDOM_SEEDS = tuple(range(8))
+
+
+def test_random_programs_around_the_pattern_are_rewritten(monkeypatch):
+  monkeypatch.setenv('SODA_HIP_RSQRT', 'g')
+  dims = set()
+  for seed in RANDOM_SEEDS:
+    text, extent = _random_program(seed)
+    st = core.from_text(text)
+    dims.add(st.dim)
+    for strategy in ('auto', 'direct'):
+      mod = lower.lower(st, lower.LowerOptions(strategy=strategy, peel=0))
+      src = mod.source
+      assert src.count('soda_rsqrt_lb(') >= 3, (seed, strategy)
+      assert 'sqrtf(' not in src.split('SODA_DEV float soda_rsqrt_lb')[1]
+  assert dims == {1, 2, 3}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('strategy', ['auto', 'direct'])
+@pytest.mark.parametrize('seed', RANDOM_SEEDS)
+def test_random_programs_around_the_pattern_keep_the_oracles_bits(seed, strategy):
+  """... against the C oracle by bits, on inputs whose magnitudes run from
+  1e-15 to 1e15 (x from the constant alone up to 1e30 and, for a few cells,
+  +inf), through the marching and the direct kernels."""
+  from oracle import c_oracle
+  from soda_amd import runtime
+  text, extent = _random_program(seed)
+  st = core.from_text(text)
+  rng = np.random.default_rng(seed)
+  shape = extent[::-1]
+  a = ((1 + rng.random(shape)) * np.power(10.0, rng.integers(-15, 16, shape)) *
+       rng.choice([-1.0, 1.0], shape)).astype(np.float32)
+  a[rng.random(shape) < 2e-3] = 3e22
+  ins = {'u': a}
+  want = c_oracle.COracle(st).run(ins)
+  with runtime.Program(st, lower.LowerOptions(strategy=strategy),
+                       extent=extent) as prog:
+    assert 'soda_rsqrt_lb(' in prog.module.source
+    got = prog.run(ins)
+  lo, hi = st.valid_box(extent, 'o')
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  g, w = got['o'][idx], want['o'][idx]
+  same = (g.view(np.int32) == w.view(np.int32)) | (np.isnan(g) & np.isnan(w))
+  assert same.all(), (seed, strategy, int((~same).sum()))
+  assert np.isfinite(w).mean() > 0.5
