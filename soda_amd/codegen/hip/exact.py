@@ -79,10 +79,13 @@ SODA_DEV float soda_rsqrt_lb(float x) {
 ''',
 }
 
-# (Refuted by the enumeration and not kept here, tools/experiments/
-# r05_rsqrt_exact.hip b / f: v_rsq seeding root and reciprocal -- one
-# transcendental instead of two -- differs for 224 of 1.9e9 operands; e: a
-# select on +inf instead of v_div_fixup returns other NaN payloads.)
+# (Refuted by the enumeration and not kept here -- profiles/
+# r05_rsqrt_candidates.json: b / f, v_rsq seeding root and reciprocal, one
+# transcendental instead of two: 224 of 1.9e9 operands differ; e, a select on
+# +inf instead of v_div_fixup: other NaN payloads; h / i / k / l, the root by one
+# fused Newton step from v_sqrt with v_rcp or v_rsq as slope: 113-561 operands
+# and +inf.  None of them ran faster in the denoise kernels than `g`
+# (profiles/r05_rsqrt_variants.jsonl): the quotient is no longer what binds.)
 
 # What the lowering emits when SODA_HIP_RSQRT is not set ('off': the program
 # as written).  Only a variant with ZERO mismatches in
