@@ -194,6 +194,37 @@ class LowerOptions:
         self.tile_rows)
 
 
+# operations per cell (as written) between which a one-iteration 2-D program
+# of fp32 cells runs on narrow strips (prefers_narrow_strips)
+NARROW_STRIP_OPS = (48, 128)
+
+
+def prefers_narrow_strips(stencil: core.Stencil) -> bool:
+  """One iteration per launch of a 2-D program that computes for 50-130
+  operations per fp32 cell (denoise2d: 55): the kernel is bound by neither
+  HBM nor the load queue but by how many waves can take turns, so 8 bytes per
+  lane with 4 rows in flight (80 registers, six waves per SIMD) beat the usual
+  16 bytes with 8 rows (127 registers, four waves): denoise2d 8192^2 171.6 /
+  170.6 us -> 164.2 / 164.2 at 8 bytes per lane -> 157.9 with 4 rows in flight
+  as well (4 bytes per lane 197.5; 16 bytes with 4 rows 168.0; 12 rows 176.6;
+  profiles/r05_denoise_shapes.jsonl, one process).  Above the band a program
+  goes through `ldswin` or takes 2 rows in flight (lower()); below it the
+  loads are what a wave waits for.  fp32 cells only: that is what was
+  measured.  runtime.resolve_options applies it where the caller fixed neither
+  the cells per lane nor the prefetch depth."""
+  if os.environ.get('SODA_HIP_NARROW', '1') == '0':
+    return False
+  if stencil.dim != 2 or stencil.iterate != 1:
+    return False
+  if any(str(t) != 'float' for t in stencil.symbol_table.values()):
+    return False
+  from soda_amd import ir as _ir
+  work = sum(_ir.op_count(s.stmt.expr) +
+             sum(_ir.op_count(l.expr) for l in s.stmt.let)
+             for s in stencil.ordered_stages)
+  return NARROW_STRIP_OPS[0] <= work < NARROW_STRIP_OPS[1]
+
+
 def default_pipe(fused_iters: int) -> int:
   """Waves of a block that share the fused iterations of a 2-D kernel
   (MarchConfig.pipe).  One: in kernel sweeps four waves with three iterations

@@ -824,6 +824,10 @@ def resolve_options(stencil: core.Stencil,
   out = copy.copy(opts) if opts is not None else lower.LowerOptions()
   if out.vec is None:
     out.vec = pick_vec(stencil, extent)
+    if out.prefetch is None and out.strategy in ('auto', 'march') and \
+        lower.prefers_narrow_strips(stencil):
+      # arithmetic-heavy one-iteration 2-D fp32 program: occupancy over width
+      out.vec, out.prefetch = min(out.vec, 2), 4
   if out.row_cells is None and extent is not None:
     out.row_cells = int(extent[0])   # lets blocks cover whole rows (xshare)
   probing = probe and not os.environ.get('SODA_HIP_NO_PROBE')

@@ -337,3 +337,37 @@ def test_random_programs_around_the_pattern_keep_the_oracles_bits(seed, strategy
   same = (g.view(np.int32) == w.view(np.int32)) | (np.isnan(g) & np.isnan(w))
   assert same.all(), (seed, strategy, int((~same).sum()))
   assert np.isfinite(w).mean() > 0.5
+
+
+# --- shape choice for arithmetic-heavy one-iteration programs -----------------
+
+def test_heavy_fp32_programs_take_narrow_strips():
+  """lower.prefers_narrow_strips / runtime.resolve_options: denoise2d (55
+  operations per fp32 cell, one iteration) gets 8 bytes per lane and 4 rows in
+  flight -- unless the caller fixed either; nothing else of the corpus moves,
+  nor any program with narrower or wider cells."""
+  from soda_amd import runtime
+  d2 = core.from_file(os.path.join(SODA_DIR, 'denoise2d.soda'))
+  assert lower.prefers_narrow_strips(d2)
+  got = runtime.resolve_options(d2, lower.LowerOptions(), (8192, 8192), probe=False)
+  assert (got.vec, got.prefetch) == (2, 4)
+  got = runtime.resolve_options(d2, lower.LowerOptions(), (1001, 64), probe=False)
+  assert got.vec == 1                                  # rows still decide first
+  got = runtime.resolve_options(d2, lower.LowerOptions(vec=4), (8192, 8192),
+                                probe=False)
+  assert got.vec == 4 and got.prefetch is None         # the caller's word
+  got = runtime.resolve_options(d2, lower.LowerOptions(prefetch=8), (8192, 8192),
+                                probe=False)
+  assert (got.vec, got.prefetch) == (4, 8)
+  for name in ('jacobi2d', 'blur', 'sobel2d', 'seidel2d', 'erosion', 'xcorr',
+               'contrast', 'heat3d', 'jacobi3d', 'denoise3d'):
+    st = core.from_file(os.path.join(SODA_DIR, name + '.soda'))
+    assert not lower.prefers_narrow_strips(st), name
+  # the same arithmetic on doubles or iterated: not what was measured
+  text = open(os.path.join(SODA_DIR, 'denoise2d.soda')).read()
+  assert not lower.prefers_narrow_strips(
+      core.from_text(text.replace('float', 'double')))
+  assert not lower.prefers_narrow_strips(
+      core.from_text(text.replace('iterate: 1', 'iterate: 2')
+                     .replace('input dram 0 float: f\n', '')
+                     .replace('f(0, 0)', '0.5f')))
