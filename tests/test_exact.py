@@ -371,3 +371,27 @@ def test_heavy_fp32_programs_take_narrow_strips():
       core.from_text(text.replace('iterate: 1', 'iterate: 2')
                      .replace('input dram 0 float: f\n', '')
                      .replace('f(0, 0)', '0.5f')))
+
+
+@pytest.mark.parametrize('seed', RANDOM_SEEDS)
+def test_the_two_oracles_agree_on_the_random_programs(seed):
+  """What the GPU cases above are compared with: the C oracle (gcc, sqrtss /
+  divss) against the numpy restatement (IEEE root and quotient of its own), by
+  bits, on the same kind of input -- on the CPU."""
+  from oracle import c_oracle, numpy_oracle
+  text, extent = _random_program(seed)
+  st = core.from_text(text)
+  extent = tuple(min(e, 90) for e in extent)
+  rng = np.random.default_rng(seed)
+  shape = extent[::-1]
+  a = ((1 + rng.random(shape)) * np.power(10.0, rng.integers(-15, 16, shape)) *
+       rng.choice([-1.0, 1.0], shape)).astype(np.float32)
+  a[rng.random(shape) < 2e-3] = 3e22
+  with np.errstate(all='ignore'):
+    n = numpy_oracle.run(st, {'u': a})['o']
+  c = c_oracle.COracle(st).run({'u': a})['o']
+  lo, hi = st.valid_box(extent, 'o')
+  idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+  g, w = n[idx], c[idx]
+  same = (g.view(np.int32) == w.view(np.int32)) | (np.isnan(g) & np.isnan(w))
+  assert same.all(), int((~same).sum())
