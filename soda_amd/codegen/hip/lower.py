@@ -208,12 +208,11 @@ def prefers_narrow_strips(stencil: core.Stencil) -> bool:
   170.6 us -> 164.2 / 164.2 at 8 bytes per lane -> 157.9 with 4 rows in flight
   as well (4 bytes per lane 197.5; 16 bytes with 4 rows 168.0; 12 rows 176.6;
   profiles/r05_denoise_shapes.jsonl, one process; sustained over 900 launches
-  each, alternating: 163.6 against 151.8 us, r05_denoise_sustained.json).  Above
-  the band a program
-  goes through `ldswin` or takes 2 rows in flight (lower()); below it the
-  loads are what a wave waits for.  fp32 cells only: that is what was
-  measured.  runtime.resolve_options applies it where the caller fixed neither
-  the cells per lane nor the prefetch depth."""
+  each, alternating: 163.6 against 151.8 us, r05_denoise_sustained.json).
+  Above the band a program goes through `ldswin` or takes 2 rows in flight
+  (lower()); below it the loads are what a wave waits for.  fp32 cells only:
+  that is what was measured.  runtime.resolve_options applies it where the
+  caller fixed neither the cells per lane nor the prefetch depth."""
   if os.environ.get('SODA_HIP_NARROW', '1') == '0':
     return False
   if stencil.dim != 2 or stencil.iterate != 1:
