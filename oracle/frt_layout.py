@@ -200,3 +200,116 @@ def kernel_on_dense_view(layout, in_banks):
     for b in range(nb):
       out_banks[o][b][:len(wire[b::nb])] = wire[b::nb]
   return out_banks
+
+
+# ---------------------------------------------------------------------------
+# The host's run-time constants, restated from the reference text alone
+# ---------------------------------------------------------------------------
+# Everything above takes its sizes from soda_amd.stream.WireLayout, the
+# product's own restatement: a constant wrong in both places would pass
+# (VERDICT r4, weak 6).  `sizes` derives the same numbers a second time,
+# from the parsed program's taps only -- its own window search, its own
+# serialisation -- following the reference formula by formula;
+# tests/test_stream.py holds the two against each other.
+
+def _serialize(vec, tile):
+  """reference src/soda/util.py:9-12."""
+  total, mul = vec[0], 1
+  for d in range(1, len(tile)):
+    mul *= tile[d - 1]
+    total += vec[d] * mul
+  return total
+
+
+def _windows(st):
+  """{output: sorted offsets of every input cell it depends on, relative to
+  its own cell} over ALL chained iterations: what the reference's recursion
+  over `tensor.parents` yields (src/soda/core.py:876-919), found here by
+  pushing offset sets through the stages in program order, output k of one
+  iteration being input k of the next (core.py:338-369)."""
+  dim = st.dim
+  zero = (0,) * dim
+  reach = {name: {name: {zero}} for name in st.input_names}  # tensor -> input -> offsets
+  reach_by_input = None
+  for it in range(st.iterate):
+    cur = {}
+    for k, name in enumerate(st.input_names):
+      if it == 0:
+        cur[name] = {name: {zero}}
+      else:
+        cur[name] = reach_by_input[st.output_names[k]]
+    for stage in st.ordered_stages:
+      mine = {}
+      for parent, taps in stage.taps.items():
+        for inp, offs in cur[parent].items():
+          bag = mine.setdefault(inp, set())
+          for t in taps:
+            for o in offs:
+              bag.add(tuple(a + b for a, b in zip(t, o)))
+      cur[stage.name] = mine
+    reach_by_input = cur
+  out = {}
+  for o in st.output_names:
+    pts = set()
+    for offs in reach_by_input[o].values():
+      pts |= offs
+    out[o] = sorted(pts)
+  return out
+
+
+def sizes(st, extent):
+  """The constants of the generated host for `extent` as a dict, keyed like
+  WireLayout's attributes (reference frt/host.py line numbers in comments)."""
+  dim = st.dim
+  tile = list(st.tile_size)
+  table = st.symbol_table
+  stmts = st.input_stmts + st.output_stmts
+  windows = _windows(st)
+  win0 = windows[st.output_names[0]]            # core.py:616-619
+  out = {}
+  out['bank_count'] = {s.name: len(s.dram) for s in stmts}               # :105-112
+  out['epc'] = {s.name: st.burst_width // table[s.name].width_in_bits *
+                out['bank_count'][s.name] for s in stmts}                # :120-122
+  out['stencil_dim'] = [max(p[d] for p in win0) - min(p[d] for p in win0) + 1
+                        for d in range(dim)]                             # core.py:864-870
+
+  def distance(points):                                                  # core.py:858-861
+    offset = tuple(-min(p[d] for p in points) for d in range(dim))       # core.py:922-926
+    return max(_serialize(p, tile) for p in points) + _serialize(offset, tile), offset
+
+  dist0, off0 = distance(win0)
+  out['stencil_distance'] = max(dist0, dist0 - _serialize(off0, tile))   # core.py:620-625
+  out['tile_count'] = [(extent[d] - out['stencil_dim'][d] + 1 - 1) //
+                       (tile[d] - out['stencil_dim'][d] + 1) + 1
+                       for d in range(dim - 1)]                          # :124-128
+  tiles = 1
+  for c in out['tile_count']:
+    tiles *= c
+  out['tiles'] = tiles                                                   # :130
+  per_tile = extent[dim - 1]
+  for d in range(dim - 1):
+    per_tile *= tile[d]
+  out['elem_count_per_tile'] = per_tile                                  # :137-139
+  in0, out0 = st.input_names[0], st.output_names[0]
+  cycles = (per_tile - 1) // out['epc'][in0] + 1                         # :140-141
+  out['cycle_count_per_tile'] = cycles
+  out['aligned_per_tile_i'] = cycles * out['epc'][in0]                   # :142-143
+  out['aligned_per_tile_o'] = cycles * out['epc'][out0]                  # :144-145
+
+  def round_up(a, b):                                                    # :115-116
+    return ((a - 1) // b + 1) * b
+
+  out['buf_elems'] = {}
+  for s in st.input_stmts:                                               # :151-156
+    out['buf_elems'][s.name] = tiles * out['aligned_per_tile_i'] + round_up(
+        out['stencil_distance'], out['epc'][s.name])
+  for s in st.output_stmts:                                              # :157-162
+    out['buf_elems'][s.name] = tiles * out['aligned_per_tile_o'] + round_up(
+        out['stencil_distance'], out['epc'][s.name])
+  out['cycle_count'] = (per_tile * tiles + out['stencil_distance'] - 1
+                        ) // out['epc'][in0] + 1                         # :272-276
+  out['stencil_offset'] = {}
+  for s in st.output_stmts:                                              # :395-403
+    d, off = distance(windows[s.name])
+    out['stencil_offset'][s.name] = d - _serialize(off, tile)
+  return out

@@ -513,7 +513,18 @@ class Stencil:
 
   @property
   def stencil_distance(self) -> int:
-    return get_stencil_distance(self.stencil_window, self.tile_size)
+    """kStencilDistance as the reference's Stencil holds it (core.py:616-625):
+    the larger of the window's distance and its stencil offset.  They differ
+    when every tap lies AHEAD of the cell in streaming order (`o(0, 0) = i(-1,
+    2)` on 32-cell rows: distance 0, offset 63 -- the host's void tail and
+    cycle count must cover the 63).  Rounds 1-5 returned the bare distance
+    here; a second derivation of the host's constants in the test
+    infrastructure (tests/test_stream.py) found it."""
+    window = self.stencil_window
+    distance = get_stencil_distance(window, self.tile_size)
+    offset = distance - util.serialize(get_stencil_window_offset(window),
+                                       self.tile_size)
+    return max(distance, offset)
 
   @property
   def stencil_dim(self) -> List[int]:

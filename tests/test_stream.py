@@ -506,3 +506,94 @@ def test_committed_wire_vectors(tag):
   frt_layout.gather(lay, out_banks, got)
   for o in st.output_names:
     assert got[o].any() and np.array_equal(got[o], gold['out_' + o]), o
+
+
+def _same_sizes(lay, want):
+  diffs = []
+  for key, val in want.items():
+    got = getattr(lay, key)
+    if isinstance(val, dict):
+      got = dict(got)
+    elif isinstance(val, list):
+      got = list(got)
+    if got != val:
+      diffs.append((key, got, val))
+  return diffs
+
+
+def test_wire_constants_agree_with_a_second_derivation():
+  """oracle/frt_layout.py drives the wire cases with sizes
+  taken from the product's WireLayout -- a constant wrong in both would pass.
+  frt_layout.sizes() derives every one of them a second time from the parsed
+  taps alone (its own window search over the chained iterations, its own
+  serialisation), formula by formula from the reference text
+  (frt/host.py:105-162, 272-276, 395-403; core.py:616-625, 858-870, 922-926).
+  The corpus (the reference's KAT distances 4002 / 130 / 4162 among them),
+  banked variants and random programs, several extents each."""
+  import glob
+  import os
+  import re
+  import fuzz
+  from conftest import SODA_DIR
+  from oracle import frt_layout
+  from soda_amd import util
+  programs = []
+  for path in sorted(glob.glob(os.path.join(SODA_DIR, '*.soda'))):
+    text = open(path).read()
+    programs.append(text)
+    # two and four banks per tensor, the reference's `dram 0.1` spelling
+    programs.append(re.sub(r'dram (\d+)\b(?!\.)', r'dram \1.\1', text))
+  for seed in range(60):
+    programs.append(fuzz.program(seed)[0])
+    programs.append(fuzz.program(seed, rich=True)[0])
+  for seed in range(30):
+    programs.append(fuzz.window_program(seed)[0])
+  checked = kat = 0
+  for text in programs:
+    try:
+      st = core.from_text(text)
+    except util.SodaError:
+      continue
+    for scale in (1, 3):
+      extent = [t * scale + 5 for t in st.tile_size[:-1]] + [23 * scale]
+      try:
+        lay = stream.WireLayout(st, extent)
+      except util.SodaError:
+        continue          # (refusals are tested where they are made)
+      want = frt_layout.sizes(st, extent)
+      assert not _same_sizes(lay, want), (st.app_name, extent)
+      checked += 1
+      if st.app_name in ('blur', 'jacobi2d', 'heat3d') and \
+          want['stencil_distance'] in (4002, 130, 4162):
+        kat += 1
+  assert checked > 150 and kat >= 6, (checked, kat)
+
+
+def test_distance_of_windows_that_lie_ahead_of_the_cell():
+  """reference core.py:616-625: kStencilDistance is max(distance, stencil
+  offset).  When every tap lies ahead of the cell in streaming order the bare
+  distance is smaller (here 0 against 63, 32 against 63) and a host that sized
+  its void tail and cycle count by it would cut the last outputs off.  Found by
+  test_wire_constants_agree_with_a_second_derivation; the whole chain --
+  scatter, the kernel contract, gather -- then returns the n-D result."""
+  from oracle import frt_layout, numpy_oracle
+  for expr, want in (('i(-1, 2)', 63), ('i(-1, 2) + i(0, 1)', 63),
+                     ('i(1, 0) + i(0, 0)', 1)):
+    st = core.from_text('kernel: ahead\nburst width: 64\nunroll factor: 2\n'
+                        'iterate: 1\ninput int32: i(32, *)\n'
+                        'output int32: o(0, 0) = %s\n' % expr)
+    assert st.stencil_distance == want, expr
+    bare = core.get_stencil_distance(st.stencil_window, st.tile_size)
+    assert bare <= want
+    extent = (32, 11)
+    lay = stream.WireLayout(st, extent)
+    assert not _same_sizes(lay, frt_layout.sizes(st, extent))
+    rng = np.random.default_rng(4)
+    ins = {'i': rng.integers(-99, 99, extent[::-1]).astype(np.int32)}
+    banks = frt_layout.scatter(lay, ins)
+    got = {'o': np.zeros(extent[::-1], np.int32)}
+    frt_layout.gather(lay, frt_layout.kernel_on_streams(lay, banks), got)
+    ref = numpy_oracle.run(st, ins)
+    lo, hi = st.valid_box(extent)
+    idx = tuple(slice(l, h) for l, h in zip(lo[::-1], hi[::-1]))
+    assert np.array_equal(got['o'][idx], ref['o'][idx]), expr
