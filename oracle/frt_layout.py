@@ -313,3 +313,23 @@ def sizes(st, extent):
     d, off = distance(windows[s.name])
     out['stencil_offset'][s.name] = d - _serialize(off, tile)
   return out
+
+
+def valid_boxes(st, extent):
+  """{output: (lo, hi)} -- the loop bounds of the reference's self-check nest
+  (frt/host.py:565-577) from the windows found HERE (`_windows`): per
+  dimension from max(0, -min) to extent - max(0, max) of the overall window
+  over the INPUTS.  The reference bounds every tensor's loop that way, so a
+  cell inside these bounds may still read a LOCAL outside the local's own
+  array (`loc(0,0,0) = in(0,0,1); out(0,0,0) = loc(0,0,-1)`: row 0 of `out`
+  reads row -1 of `loc`, undefined behaviour in the reference's C++).  The
+  product's boxes (core.iteration_boxes) also keep every intermediate inside
+  its own box, so they lie INSIDE these and equal them for programs whose
+  outputs read inputs only."""
+  out = {}
+  for o, pts in _windows(st).items():
+    lo = tuple(max(0, -min(p[d] for p in pts)) for d in range(st.dim))
+    hi = tuple(extent[d] - max(0, max(p[d] for p in pts))
+               for d in range(st.dim))
+    out[o] = (lo, hi)
+  return out

@@ -548,7 +548,7 @@ def test_wire_constants_agree_with_a_second_derivation():
     programs.append(fuzz.program(seed, rich=True)[0])
   for seed in range(30):
     programs.append(fuzz.window_program(seed)[0])
-  checked = kat = 0
+  checked = kat = boxes_equal = 0
   for text in programs:
     try:
       st = core.from_text(text)
@@ -562,11 +562,24 @@ def test_wire_constants_agree_with_a_second_derivation():
         continue          # (refusals are tested where they are made)
       want = frt_layout.sizes(st, extent)
       assert not _same_sizes(lay, want), (st.app_name, extent)
+      # ... and, from the same second window search, the valid boxes every
+      # parity test compares inside (reference frt/host.py:565-577)
+      # (the product also keeps every local inside its own box: inside the
+      # reference's bounds always, equal where outputs read inputs only)
+      direct = not st.local_stmts and st.iterate == 1
+      for o, (lo, hi) in frt_layout.valid_boxes(st, extent).items():
+        got_lo, got_hi = st.valid_box(extent, o)
+        assert all(g >= l for g, l in zip(got_lo, lo)), (st.app_name, o)
+        assert all(g <= h for g, h in zip(got_hi, hi)), (st.app_name, o)
+        if direct:
+          assert (tuple(got_lo), tuple(got_hi)) == (lo, hi), (st.app_name, o)
+          boxes_equal += 1
       checked += 1
       if st.app_name in ('blur', 'jacobi2d', 'heat3d') and \
           want['stencil_distance'] in (4002, 130, 4162):
         kat += 1
-  assert checked > 150 and kat >= 6, (checked, kat)
+  assert checked > 150 and kat >= 6 and boxes_equal >= 30, (
+      checked, kat, boxes_equal)
 
 
 def test_distance_of_windows_that_lie_ahead_of_the_cell():
