@@ -35,3 +35,10 @@ print('value %.4g  ms/step %.4f  frac %.3f  bound %s  traffic %s  valu %s' % (
 assert r.get('traffic'), r.get('traffic_dropped')
 PY
 cat $out/${tag}_hostpath.jsonl
+# 5. the enumeration behind codegen/hip/exact.py (1.9e9 operands, ~1 s): its
+#    record is keyed by the text of the sequence the kernels use
+#    (tests/test_exact.py::test_the_committed_enumeration_is_for_this_text)
+python -m pytest tests/test_exact.py -m gpu -q -k every_operand > $out/${tag}_rsqrt_exact.log 2>&1 && \
+  cp $out/rsqrt_exact.json $out/${tag}_rsqrt_exact.json
+tail -1 $out/${tag}_rsqrt_exact.log
+echo "(copy $out/${tag}_rsqrt_exact.json to profiles/rsqrt_exact.json if exact.py's text changed)"
