@@ -623,7 +623,9 @@ typedef struct soda_hip_stream_desc {
   int32_t num_outputs;
   int32_t iterate;
   int32_t tile[SODA_HIP_MAX_DIM];      /* tile size of dimensions 0..dim-2 */
-  int32_t stencil_distance;            /* kStencilDistance (frt/host.py:683-696) */
+  int32_t stencil_distance;            /* kStencilDistance (frt/host.py:683-696) =
+                                        * max(window distance, stencil offset),
+                                        * reference core.py:620-625 */
   /* per tensor, inputs first, then outputs */
   int32_t banks[SODA_HIP_MAX_TENSORS];
   int32_t elem_size[SODA_HIP_MAX_TENSORS];
