@@ -357,3 +357,87 @@ def test_pack_and_unpack_from_several_caller_threads(built):
     t.join(timeout=120)
   assert not any(t.is_alive() for t in threads), 'a caller never returned'
   assert not errors, errors
+
+
+def test_numpy_host_against_the_transcribed_host(tmp_path):
+  """oracle/frt_layout.py (scatter, gather: what every wire case on the GPU is
+  driven by) against tests/host/frt_host.h (the reference host transcribed to
+  C++ from the same text, written separately) on random layouts: one to
+  several tiles per dimension, ragged last tiles, one to four banks a side,
+  2-D and 3-D, windows that are not centred.  The kernel in between only
+  records -- input banks as laid out, output banks filled with their own
+  stream positions -- so every element of every bank and every gathered cell
+  is compared (cells the host never writes included).  Under ASan + UBSan."""
+  import numpy as np
+  from oracle import frt_layout
+  from soda_amd import core, stream, util
+  exe = os.path.join(str(tmp_path), 'frt_dump')
+  host = os.path.join(ROOT, 'tests', 'host')
+  subprocess.run(['g++', '-std=c++17', '-O1', '-Wall', '-Werror',
+                  '-fsanitize=address,undefined',
+                  os.path.join(host, 'frt_dump_main.cpp'), '-o', exe],
+                 check=True)
+  rng = np.random.default_rng(77)
+  ran = multi_tile = banked = gathered = 0
+  for trial in range(40):
+    dim = 2 if trial % 3 else 3
+    tile = [int(rng.choice([8, 16, 32])) for _ in range(dim - 1)]
+    taps = {tuple(int(rng.integers(-2, 3)) for _ in range(dim))
+            for _ in range(int(rng.integers(1, 5)))}
+    taps.add((0,) * dim)
+    nb_in = int(rng.integers(1, 5))
+    # (banks a side differ in a quarter of the trials: the reference host sizes
+    # an output tile in cycles of the INPUT's elements per cycle,
+    # frt/host.py:140-145, and then gathers past its own buffer -- the product
+    # refuses such programs (DESIGN.md 4.4); only the scatter is compared)
+    nb_out = nb_in if trial % 4 else int(rng.integers(1, 5))
+    text = ('kernel: lay%d\nburst width: 64\nunroll factor: 2\niterate: 1\n'
+            'input dram %s int32: i(%s, *)\n'
+            'output dram %s int32: o(%s) = %s\n' % (
+                trial, '.'.join(map(str, range(nb_in))),
+                ', '.join(map(str, tile)),
+                '.'.join(map(str, range(nb_out))), ', '.join(['0'] * dim),
+                ' + '.join('i(%s)' % ', '.join(map(str, t))
+                           for t in sorted(taps))))
+    st = core.from_text(text)
+    extent = [int(rng.integers(t // 2 + 3, 3 * t)) for t in tile] + \
+        [int(rng.integers(5, 12))]
+    try:
+      lay = stream.WireLayout(st, extent)
+    except util.SodaError:
+      continue
+    window = st.stencil_window
+    sdim = core.get_stencil_dim(window)
+    woff = core.get_stencil_window_offset(window)
+    argv = [exe, str(dim), '64', str(nb_in), str(nb_out),
+            str(st.stencil_distance)]
+    for d in range(dim):
+      argv += [str(extent[d]), str(tile[d] if d < dim - 1 else 0),
+               str(sdim[d]), str(woff[d])]
+    run = subprocess.run(argv, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (text, extent, run.stdout[-300:], run.stderr)
+    lines = run.stdout.split('\n')
+    assert int(lines[0].split()[1]) == lay.cycle_count, (text, extent)
+    cells = int(np.prod(extent))
+    field = (np.arange(cells, dtype=np.int64) * 7 + 3).astype(np.int32)
+    banks = frt_layout.scatter(lay, {'i': field.reshape(extent[::-1])})
+    for b in range(nb_in):
+      got = np.array(lines[1 + b].split()[2:], dtype=np.int64)
+      assert np.array_equal(got, banks['i'][b].astype(np.int64)), (
+          text, extent, 'input bank %d' % b)
+    ran += 1
+    multi_tile += lay.tiles > 1
+    banked += nb_in > 1
+    if nb_out != nb_in:
+      continue
+    out_banks = frt_layout.alloc(lay, ['o'])
+    for b in range(nb_out):
+      n = len(out_banks['o'][b])
+      out_banks['o'][b][:] = 1000000 + np.arange(n) * nb_out + b
+    mine = {'o': np.full(extent[::-1], -1, np.int32)}
+    frt_layout.gather(lay, out_banks, mine)
+    theirs = np.array(lines[1 + nb_in].split()[1:], dtype=np.int64)
+    assert np.array_equal(theirs, mine['o'].reshape(-1).astype(np.int64)), (
+        text, extent, 'gathered array')
+    gathered += 1
+  assert gathered >= 18 and ran >= 25 and multi_tile >= 8 and banked >= 15, (ran, multi_tile, banked)
